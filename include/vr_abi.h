@@ -1,0 +1,135 @@
+/*
+ * C ABI of the MI355X direct-volume-rendering core (libvr_hip.so).
+ *
+ * The library replaces the VolumeRendering application's GPU path of the reference — the
+ * Vulkan compute pipeline that the application records every frame — by HIP kernels for
+ * gfx950.  Each entry point names the reference code it stands in for (paths relative to the
+ * reference checkout).  Conventions: every function returns 0 on success or a negative
+ * VR_ERR_* code; the message of the last failure of a context is available from
+ * vr_last_error(); no exception crosses this boundary (the reference throws
+ * std::runtime_error and catches once in VulkanApplication::run, Source/VulkanApplication.cpp:
+ * 188-217).  A context belongs to one GPU and is not thread-safe, like the reference's single
+ * render thread; different contexts may be used from different threads.  Host pointers are
+ * borrowed for the duration of the call only.  All work is issued on the context's stream.
+ */
+#ifndef VR_ABI_H
+#define VR_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VR_OK 0
+#define VR_ERR_ARG (-1)      /* invalid argument */
+#define VR_ERR_HIP (-2)      /* a HIP runtime call failed */
+#define VR_ERR_STATE (-3)    /* call order violated (e.g. render before upload) */
+#define VR_ERR_IO (-4)       /* file system error while reading slices */
+
+#define VR_DTYPE_U8 1
+#define VR_DTYPE_U16 2
+
+/* Render strategies.  Both produce the frame the reference shader defines. */
+#define VR_MODE_REFERENCE_ORDER 0 /* back-to-front, every tap (VolumeRendering.comp:183-202) */
+#define VR_MODE_FAST 1            /* front-to-back, macrocell skipping, early termination */
+
+typedef struct vr_ctx vr_ctx;
+
+/* One control point of a transfer-function control graph: ControlPoint{position.x, intensity},
+ * Applications/VolumeRendering/Source/main.cpp:101-105 (position.y only feeds intensity). */
+typedef struct vr_ctrl_pt {
+    float x;
+    float intensity;
+} vr_ctrl_pt;
+
+/* Work and traffic counters of one frame (filled only when a stats pointer is passed; the
+ * counting variant of the kernels is slower than the plain one). */
+typedef struct vr_stats {
+    uint64_t rays;              /* pixels rendered by this call */
+    uint64_t rays_hit;          /* rays that hit the volume box */
+    uint64_t samples_nominal;   /* rays_hit * (samples_per_ray + 2): taps the reference executes */
+    uint64_t samples_evaluated; /* trilinear taps actually fetched */
+    uint64_t cells_read;        /* macrocell (min,max) entries read */
+    uint64_t bricks_touched;    /* distinct 8^3 bricks holding a voxel of an evaluated tap */
+    uint64_t replay_rays;       /* rays re-marched in reference order by the fast mode */
+    uint64_t algorithmic_bytes; /* 1024 B (u16; 512 B u8) * bricks_touched + 4 B * distinct cells
+                                   + LUT + 4 B * rays */
+    float kernel_ms;            /* device time of the frame's kernels (hipEvent) */
+} vr_stats;
+
+/* Context life cycle.  Stands in for initComputePipeline / postRenderLoop,
+ * main.cpp:203-573 and 1246-1283. */
+int vr_create(int device, vr_ctx **out);
+int vr_destroy(vr_ctx *ctx);
+const char *vr_last_error(const vr_ctx *ctx);
+/* The HIP stream all work of the context is issued on (a hipStream_t). */
+void *vr_stream(vr_ctx *ctx);
+int vr_synchronize(vr_ctx *ctx);
+
+/* Volume upload: loadVolumeData's normalisation (main.cpp:144,161-164) + the staging copy into
+ * the 3-D image (main.cpp:260-280, 601-613).  voxels: nx*ny*nz values, x fastest, then y, then
+ * slice, little-endian.  max_value <= 0: use the data maximum, as the reference does; a
+ * positive value must not be below the data maximum.  The volume is re-tiled into 8^3 bricks
+ * and a per-brick (min,max) macrocell grid is built.  vr_upload_volume takes a host pointer,
+ * vr_upload_volume_device a device pointer on the context's GPU. */
+int vr_upload_volume(vr_ctx *ctx, const void *voxels, int dtype, int nx, int ny, int nz, float max_value);
+int vr_upload_volume_device(vr_ctx *ctx, const void *d_voxels, int dtype, int nx, int ny, int nz, float max_value);
+
+/* loadVolumeData, main.cpp:112-165: every file of the directory, ordered by the integer after
+ * the last dot (or the whole name), headerless big-endian u16, width = height =
+ * floor(sqrt(values in the first slice)).  Byte swap, maximum and re-tiling run on the GPU. */
+int vr_load_volume_slices(vr_ctx *ctx, const char *directory);
+int vr_volume_info(const vr_ctx *ctx, int *nx, int *ny, int *nz, int *dtype, float *max_value);
+/* Normalised float copy of the resident volume (what the reference keeps in `intensities`,
+ * main.cpp:39), written to a host buffer of nx*ny*nz floats.  For checks. */
+int vr_read_volume_normalized(vr_ctx *ctx, float *out);
+
+/* updateTransferFunction, main.cpp:643-686, plus the upload of the table, main.cpp:687-736.
+ * points[c] / counts[c]: control graph of channel c (R,G,B,A), sorted by x.  The table lives on
+ * the GPU and persists between calls exactly like `transferFunction` (main.cpp:110); entries no
+ * segment covers keep their previous value.  reset_state != 0 zeroes it first.  counts[c] == 0
+ * leaves channel c untouched. */
+int vr_set_transfer_function(vr_ctx *ctx, const vr_ctrl_pt *const points[4], const int counts[4], int reset_state);
+int vr_get_lut(vr_ctx *ctx, float out[1024]);
+/* getIntensity, main.cpp:948-953 */
+float vr_control_point_intensity(float y, float child_height);
+
+/* Camera: setupViewPyramid + updatePixelTransformationUniforms, main.cpp:182-202, 737-799.
+ * horizontal in [-pi, pi], vertical in [-pi/2, pi/2] (the ImGui sliders, main.cpp:1210-1211). */
+int vr_set_camera(vr_ctx *ctx, float horizontal_rad, float vertical_rad);
+/* Directly sets what the shader reads: ViewPyramid.location and PixelTransform.toWorld
+ * (VolumeRendering.comp:12-22).  to_world is column-major and is used for every image size. */
+int vr_set_camera_raw(vr_ctx *ctx, const float location[4], const float to_world[16]);
+/* The two uniform blocks for a width x height image: 80-byte ViewPyramid
+ * {height, location, side, up, forward} and the 64-byte toWorld matrix. */
+int vr_get_camera(vr_ctx *ctx, int width, int height, float view_pyramid[20], float to_world[16]);
+/* The same uniforms without a context (pure host arithmetic, usable without a GPU). */
+int vr_camera_uniforms(float horizontal_rad, float vertical_rad, int width, int height,
+                       float view_pyramid[20], float to_world[16]);
+
+/* samples_per_ray: the shader constant `samples` (VolumeRendering.comp:173, 200 there); a ray
+ * takes samples_per_ray + 2 taps.  tf_border_rgba: border colour of the sampler as seen by the
+ * transfer-function fetch (main.cpp:380), NULL keeps the current one (default 0,0,0,0). */
+int vr_set_sampling(vr_ctx *ctx, int samples_per_ray, const float tf_border_rgba[4]);
+int vr_set_mode(vr_ctx *ctx, int mode);
+
+/* One frame: the dispatch of VolumeRendering.comp (main.cpp:823-828) and its imageStore
+ * (VolumeRendering.comp:205).  out: width*height*4 bytes RGBA8, row-major, pixel (0,0) first;
+ * a host pointer (out_is_device == 0, copied back and synchronised) or a device pointer
+ * (out_is_device != 0, asynchronous on the context's stream).  stats may be NULL. */
+int vr_render(vr_ctx *ctx, int width, int height, uint8_t *out, int out_is_device, vr_stats *stats);
+/* The same for the pixel rectangle [x0,x1) x [y0,y1) of the width x height frame: out holds
+ * (x1-x0)*(y1-y0)*4 bytes, rectangle rows contiguous.  For sort-first tiling. */
+int vr_render_rect(vr_ctx *ctx, int width, int height, int x0, int y0, int x1, int y1,
+                   uint8_t *out, int out_is_device, vr_stats *stats);
+
+/* Synthetic CT phantom used as measurement input (no counterpart in the reference): n^3 voxels
+ * written to device memory, then usable with vr_upload_volume_device.  d_out: n^3 * dtype bytes. */
+int vr_phantom_generate_device(vr_ctx *ctx, void *d_out, int dtype, int n, uint32_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

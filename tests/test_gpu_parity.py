@@ -1,0 +1,296 @@
+"""GPU parity tests: every check calls the HIP path through the C ABI (libvr_hip.so) and compares
+with the CPU checker on the same inputs, or with the committed golden vectors.
+
+Bars: transfer-function table, camera uniforms, phantom and normalised voxels bit-exact; frames
+at most 1/255 per channel off with at least 99.9 % of the pixels identical (the kernels are built
+to be bit-identical to the checker, which the tests also report and assert)."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+import conftest as cf
+
+pytestmark = pytest.mark.gpu
+
+MAX_DELTA = 1          # 1/255 per RGBA8 channel
+MIN_EXACT = 0.999      # fraction of identical pixels
+
+
+@pytest.fixture(scope="module")
+def vr():
+    import vulkanrenderer_amd as m
+    return m
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+    assert t.cuda.is_available()
+    return t
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(os.path.join(cf.GOLDEN, "golden.npz"))
+
+
+@pytest.fixture()
+def ctx(vr):
+    c = vr.VolumeRenderer(0)
+    yield c
+    c.close()
+
+
+def check_frame(got, want, what, exact_required=True):
+    worst, exact = cf.frame_report(got, want)
+    print("%s: max|delta|=%d exact=%.5f" % (what, worst, exact))
+    assert worst <= MAX_DELTA and exact >= MIN_EXACT, what
+    if exact_required:
+        assert exact == 1.0, what
+    assert np.all(got[..., 3] == 255)
+
+
+# ---- transfer function (bit-exact) ------------------------------------------------------------
+
+def test_lut_bit_exact_all_cases(ctx, oracle, golden):
+    for name, updates in cf.lut_cases().items():
+        want = np.zeros((256, 4), np.float32)
+        for k, graphs in enumerate(updates):
+            oracle.lut_update(want, graphs)
+            ctx.update_transfer_function(graphs, reset_state=(k == 0))
+            assert cf.same_bits(ctx.transfer_function(), want), (name, k)
+        assert cf.same_bits(ctx.transfer_function(), golden["lut_" + name]), name
+
+
+def test_lut_random_graphs_bit_exact(ctx, oracle):
+    rng = np.random.default_rng(11)
+    want = np.zeros((256, 4), np.float32)
+    ctx.update_transfer_function([[], [], [], []], reset_state=True)
+    for trial in range(40):
+        graphs = []
+        for c in range(4):
+            n = int(rng.integers(2, 17))
+            xs = np.sort(rng.integers(0, 483, size=n).astype(np.float32))
+            if rng.random() < 0.5:
+                xs += rng.random(n).astype(np.float32)     # fractional pixel positions
+                xs = np.sort(xs)
+            xs[0] = 0.0
+            if xs[-1] <= 0:
+                xs[-1] = 482.0
+            ys = rng.random(n).astype(np.float32)
+            graphs.append(list(zip(xs.tolist(), ys.tolist())))
+        oracle.lut_update(want, graphs)
+        ctx.update_transfer_function(graphs)
+        assert cf.same_bits(ctx.transfer_function(), want), trial
+
+
+def test_lut_rejects_bad_graphs(ctx, vr):
+    with pytest.raises(vr.VrError):
+        ctx.update_transfer_function([[(10.0, 0.1), (5.0, 0.2)], [], [], []])      # not ascending
+    with pytest.raises(vr.VrError):
+        ctx.update_transfer_function([[(0.0, 0.1), (0.0, 0.2)], [], [], []])       # x_last == 0
+    with pytest.raises(vr.VrError):
+        ctx.update_transfer_function([[(-1.0, 0.1), (5.0, 0.2)], [], [], []])
+
+
+# ---- camera -----------------------------------------------------------------------------------
+
+def test_camera_uniforms_bit_exact(ctx, oracle, golden):
+    for cname, (h, v) in cf.CAMERAS.items():
+        ctx.set_camera(h, v)
+        for (w, hgt) in ((512, 512), (1280, 720)):
+            vp, m = ctx.pixel_transformation_uniforms(w, hgt)
+            assert cf.same_bits(vp, golden["cam_%s_%dx%d_vp" % (cname, w, hgt)])
+            assert cf.same_bits(m, golden["cam_%s_%dx%d_m" % (cname, w, hgt)])
+
+
+# ---- ingest ------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("dtype,n", [(np.uint8, 40), (np.uint16, 37)])
+def test_phantom_device_equals_checker(ctx, oracle, torch, dtype, n):
+    tdt = torch.uint8 if dtype == np.uint8 else torch.int16
+    buf = torch.empty(n ** 3, dtype=tdt, device="cuda")
+    torch.cuda.synchronize()
+    ctx.phantom_generate_device(buf.data_ptr(), np.dtype(dtype).itemsize, n)
+    ctx.synchronize()
+    got = buf.cpu().numpy().view(dtype).reshape(n, n, n)
+    assert np.array_equal(got, oracle.phantom(n, dtype))
+
+
+@pytest.mark.parametrize("dtype,shape", [(np.uint8, (13, 21, 30)), (np.uint16, (9, 16, 23)), (np.uint16, (1, 1, 1))])
+def test_normalised_voxels_bit_exact(ctx, oracle, dtype, shape):
+    rng = np.random.default_rng(5)
+    hi = 256 if dtype == np.uint8 else 3273
+    vox = rng.integers(0, hi, size=shape).astype(dtype)
+    vox.flat[0] = hi - 1
+    ctx.upload_volume(vox)
+    want, mx = oracle.normalize(vox)
+    assert ctx.volume_info()["max_value"] == mx
+    assert cf.same_bits(ctx.read_volume_normalized(), want)
+
+
+def test_normalisation_exact_for_every_u16_value(ctx, oracle):
+    for mx in (65535, 63536, 5119, 3272, 257, 3):
+        vox = (np.arange(65536, dtype=np.uint32) % (mx + 1)).astype(np.uint16).reshape(16, 64, 64)
+        ctx.upload_volume(vox)
+        want, got_mx = oracle.normalize(vox)
+        assert got_mx == float(mx)
+        assert cf.same_bits(ctx.read_volume_normalized(), want), mx
+
+
+def test_explicit_max_value(ctx, oracle, vr):
+    vox = np.arange(4 * 4 * 4, dtype=np.uint16).reshape(4, 4, 4)
+    ctx.upload_volume(vox, max_value=1000.0)
+    assert cf.same_bits(ctx.read_volume_normalized(), oracle.normalize(vox, 1000.0)[0])
+    with pytest.raises(vr.VrError):
+        ctx.upload_volume(vox, max_value=10.0)        # below the data maximum
+    with pytest.raises(vr.VrError):
+        ctx.upload_volume(np.zeros((4, 4, 4), np.uint8))   # the reference would divide by zero
+
+
+def test_slice_loader_matches_checker(ctx, oracle, tmp_path):
+    rng = np.random.default_rng(7)
+    vol = rng.integers(0, 4000, size=(6, 24, 24)).astype(np.uint16)
+    for k in (4, 2, 6, 1, 5, 3):
+        vol[k - 1].astype(">u2").tofile(tmp_path / ("CThead.%d" % k))
+    ctx.load_volume_data(str(tmp_path))
+    want, mx = oracle.load_slices(str(tmp_path))
+    info = ctx.volume_info()
+    assert (info["nz"], info["ny"], info["nx"]) == want.shape and info["max_value"] == mx
+    assert cf.same_bits(ctx.read_volume_normalized(), want)
+
+
+def test_slice_loader_errors(ctx, vr, tmp_path):
+    with pytest.raises(vr.VrError):
+        ctx.load_volume_data(str(tmp_path / "missing"))
+    with pytest.raises(vr.VrError):
+        ctx.load_volume_data(str(tmp_path))             # empty directory (main.cpp:158)
+
+
+# ---- frames ------------------------------------------------------------------------------------
+
+def render_pair(ctx, oracle, vox, graphs, cam, w, h, samples, border=(0, 0, 0, 0), mode=0, stats=False):
+    ctx.upload_volume(vox)
+    ctx.update_transfer_function(graphs, reset_state=True)
+    ctx.set_camera(*cam)
+    ctx.set_sampling(samples, border)
+    ctx.set_mode(mode)
+    got = ctx.render(w, h, stats=stats)
+    vol, _ = oracle.normalize(vox)
+    lut = np.zeros((256, 4), np.float32)
+    oracle.lut_update(lut, graphs)
+    vp, m = oracle.camera(cam[0], cam[1], w, h)
+    want = oracle.render(vol, lut, vp[4:8], m, w, h, samples, border=border)
+    return got, want
+
+
+@pytest.mark.parametrize("mode", [0])
+def test_golden_frames(ctx, oracle, golden, mode):
+    for dtype, n, tag in ((np.uint8, 32, "u8_32"), (np.uint16, 64, "u16_64")):
+        ctx.upload_volume(oracle.phantom(n, dtype))
+        ctx.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+        ctx.set_sampling(200, (0, 0, 0, 0))
+        ctx.set_mode(mode)
+        for cname, cam in cf.CAMERAS.items():
+            ctx.set_camera(*cam)
+            check_frame(ctx.render(64, 64), golden["frame_%s_%s" % (tag, cname)], "golden %s %s mode %d" % (tag, cname, mode))
+
+
+@pytest.mark.parametrize("mode", [0])
+@pytest.mark.parametrize("w,h", [(50, 37), (129, 65), (16, 16)])
+def test_ragged_image_sizes(ctx, oracle, mode, w, h):
+    got, want = render_pair(ctx, oracle, oracle.phantom(24, np.uint16), cf.TF_GRAPHS, cf.CAMERAS["h30_v20"], w, h, 60, mode=mode)
+    check_frame(got, want, "ragged %dx%d" % (w, h))
+
+
+@pytest.mark.parametrize("mode", [0])
+def test_non_cubic_volume_and_border_colour(ctx, oracle, mode):
+    rng = np.random.default_rng(9)
+    vox = rng.integers(0, 3000, size=(11, 33, 20)).astype(np.uint16)      # nz, ny, nx all different
+    for border in ((0, 0, 0, 0), (0, 0, 0, 1), (0.2, 0.4, 0.6, 0.3)):
+        got, want = render_pair(ctx, oracle, vox, cf.TF_GRAPHS, cf.CAMERAS["hm135_vm60"], 96, 80, 100, border=border, mode=mode)
+        check_frame(got, want, "noise volume border %s" % (border,))
+
+
+@pytest.mark.parametrize("mode", [0])
+def test_config1_full_size(ctx, oracle, mode):
+    # BASELINE configs[0]: 256^3 uint8 phantom, 512x512, fixed camera (30, 20 degrees), 4-point TF, 200 samples
+    got, want = render_pair(ctx, oracle, oracle.phantom(256, np.uint8), cf.TF_GRAPHS, cf.CAMERAS["h30_v20"], 512, 512, 200,
+                            mode=mode, stats=True)
+    img, st = got
+    check_frame(img, want, "config 1")
+    vp, m = oracle.camera(*cf.CAMERAS["h30_v20"], 512, 512)
+    assert st["rays"] == 512 * 512 and st["rays_hit"] == oracle.count_hits(vp[4:8], m, 512, 512)
+    assert st["samples_nominal"] == st["rays_hit"] * 202
+    if mode == 0:
+        assert st["samples_evaluated"] == st["samples_nominal"]
+    assert 0 < st["bricks_touched"] <= 33 ** 3 and st["algorithmic_bytes"] > 512 * 512 * 4
+
+
+@pytest.mark.parametrize("mode", [0])
+def test_rect_equals_crop_of_frame(ctx, oracle, mode):
+    ctx.upload_volume(oracle.phantom(32, np.uint8))
+    ctx.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+    ctx.set_camera(*cf.CAMERAS["h30_v20"])
+    ctx.set_sampling(80)
+    ctx.set_mode(mode)
+    full = ctx.render(100, 70)
+    for rect in ((0, 0, 100, 70), (16, 16, 48, 32), (37, 5, 99, 61), (99, 69, 100, 70)):
+        x0, y0, x1, y1 = rect
+        assert np.array_equal(ctx.render(100, 70, rect=rect), full[y0:y1, x0:x1]), rect
+
+
+@pytest.mark.parametrize("mode", [0])
+def test_camera_inside_the_box(ctx, oracle, mode):
+    # tMin < 0 is used as is (VolumeRendering.comp:93-95): taps behind the apex are still taken
+    vox = oracle.phantom(32, np.uint16)
+    ctx.upload_volume(vox)
+    ctx.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+    ctx.set_sampling(64)
+    ctx.set_mode(mode)
+    vp, m = oracle.camera(0.3, 0.2, 64, 64)
+    loc = np.array([0.05, -0.1, -0.45, 1.0], np.float32)
+    m = m.copy().reshape(4, 4)
+    m[3, :3] = loc[:3] + np.float32(0.2) * vp[16:19]       # image plane 0.2 in front of the apex
+    m[0, :3] *= np.float32(0.3)
+    m[1, :3] *= np.float32(0.3)
+    ctx.set_camera_raw(loc, m.ravel())
+    got = ctx.render(64, 64)
+    vol, _ = oracle.normalize(vox)
+    lut = np.zeros((256, 4), np.float32)
+    oracle.lut_update(lut, cf.TF_GRAPHS)
+    want = oracle.render(vol, lut, loc, m.ravel(), 64, 64, 64)
+    check_frame(got, want, "camera inside box")
+    assert want[..., :3].any()
+
+
+def test_device_output_pointer(ctx, oracle, torch):
+    ctx.upload_volume(oracle.phantom(32, np.uint8))
+    ctx.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+    ctx.set_camera(*cf.CAMERAS["front"])
+    ctx.set_sampling(50)
+    host = ctx.render(64, 48)
+    buf = torch.zeros(48 * 64 * 4, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.render_device(64, 48, buf.data_ptr())
+    ctx.synchronize()
+    assert np.array_equal(buf.cpu().numpy().reshape(48, 64, 4), host)
+
+
+def test_call_order_and_argument_errors(vr):
+    with vr.VolumeRenderer(0) as c:
+        with pytest.raises(vr.VrError):
+            c.render(64, 64)                                   # no volume yet
+        c.upload_volume(np.ones((4, 4, 4), np.uint8))
+        with pytest.raises(vr.VrError):
+            c.render(1, 64)                                    # 1/(extent-1), main.cpp:772
+        with pytest.raises(vr.VrError):
+            c.render(64, 64, rect=(0, 0, 65, 64))
+        with pytest.raises(vr.VrError):
+            c.set_sampling(-1)
+        with pytest.raises(vr.VrError):
+            c.set_mode(7)
+    h = vr.C.c_void_p()
+    assert vr.lib().vr_create(9999, vr.C.byref(h)) != 0

@@ -1,0 +1,236 @@
+"""MI355X-native direct-volume-rendering core: Python binding of libvr_hip.so.
+
+The product is the C-ABI library (include/vr_abi.h, vulkanrenderer_amd/csrc).  This module only
+loads it with ctypes and wraps a context in a small class whose methods are named after the
+reference functions they replace (Applications/VolumeRendering/Source/main.cpp).  There is no
+CPU fallback: if the library is missing, importing `lib()` raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvr_hip.so")
+
+DTYPE_U8, DTYPE_U16 = 1, 2
+MODE_REFERENCE_ORDER, MODE_FAST = 0, 1
+
+# every symbol include/vr_abi.h declares
+ABI_SYMBOLS = (
+    "vr_create", "vr_destroy", "vr_last_error", "vr_stream", "vr_synchronize",
+    "vr_upload_volume", "vr_upload_volume_device", "vr_load_volume_slices", "vr_volume_info",
+    "vr_read_volume_normalized", "vr_set_transfer_function", "vr_get_lut",
+    "vr_control_point_intensity", "vr_set_camera", "vr_set_camera_raw", "vr_get_camera",
+    "vr_camera_uniforms",
+    "vr_set_sampling", "vr_set_mode", "vr_render", "vr_render_rect", "vr_phantom_generate_device",
+)
+
+
+class CtrlPt(C.Structure):
+    _fields_ = [("x", C.c_float), ("intensity", C.c_float)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("rays_hit", C.c_uint64), ("samples_nominal", C.c_uint64),
+                ("samples_evaluated", C.c_uint64), ("cells_read", C.c_uint64),
+                ("bricks_touched", C.c_uint64), ("replay_rays", C.c_uint64),
+                ("algorithmic_bytes", C.c_uint64), ("kernel_ms", C.c_float)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class VrError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Loads libvr_hip.so (built by __graft_entry__.build() / csrc/Makefile); no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libvr_hip.so is not built: run `make -C vulkanrenderer_amd/csrc` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, fp = C.c_void_p, C.POINTER(C.c_float)
+    L.vr_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.vr_destroy.argtypes = [vp]
+    L.vr_last_error.argtypes = [vp]
+    L.vr_last_error.restype = C.c_char_p
+    L.vr_stream.argtypes = [vp]
+    L.vr_stream.restype = vp
+    L.vr_synchronize.argtypes = [vp]
+    L.vr_upload_volume.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]
+    L.vr_upload_volume_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]
+    L.vr_load_volume_slices.argtypes = [vp, C.c_char_p]
+    L.vr_volume_info.argtypes = [vp] + [C.POINTER(C.c_int)] * 4 + [fp]
+    L.vr_read_volume_normalized.argtypes = [vp, fp]
+    L.vr_set_transfer_function.argtypes = [vp, C.POINTER(C.POINTER(CtrlPt)), C.POINTER(C.c_int), C.c_int]
+    L.vr_get_lut.argtypes = [vp, fp]
+    L.vr_control_point_intensity.argtypes = [C.c_float, C.c_float]
+    L.vr_control_point_intensity.restype = C.c_float
+    L.vr_set_camera.argtypes = [vp, C.c_float, C.c_float]
+    L.vr_set_camera_raw.argtypes = [vp, fp, fp]
+    L.vr_get_camera.argtypes = [vp, C.c_int, C.c_int, fp, fp]
+    L.vr_camera_uniforms.argtypes = [C.c_float, C.c_float, C.c_int, C.c_int, fp, fp]
+    L.vr_set_sampling.argtypes = [vp, C.c_int, fp]
+    L.vr_set_mode.argtypes = [vp, C.c_int]
+    L.vr_render.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.POINTER(Stats)]
+    L.vr_render_rect.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.POINTER(Stats)]
+    L.vr_phantom_generate_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_uint32]
+    for name in ABI_SYMBOLS:
+        fn = getattr(L, name)
+        if name not in ("vr_last_error", "vr_stream", "vr_control_point_intensity"):
+            fn.restype = C.c_int
+    _lib = L
+    return L
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def camera_uniforms(horizontal_rad, vertical_rad, width, height):
+    """ViewPyramid block (20 floats) and toWorld (16 floats, column-major); host arithmetic only."""
+    vp = np.empty(20, np.float32)
+    m = np.empty(16, np.float32)
+    rc = lib().vr_camera_uniforms(horizontal_rad, vertical_rad, width, height, _fp(vp), _fp(m))
+    if rc != 0:
+        raise VrError("vr_camera_uniforms failed with %d" % rc)
+    return vp, m
+
+
+def control_point_intensity(y, child_height):
+    return float(lib().vr_control_point_intensity(y, child_height))
+
+
+class VolumeRenderer:
+    """One context on one GPU.  Method names follow the reference application's functions."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        rc = lib().vr_create(device, C.byref(self._h))
+        if rc != 0:
+            raise VrError("vr_create(%d) failed with %d" % (device, rc))
+
+    def close(self):
+        if self._h:
+            lib().vr_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise VrError("%s (code %d)" % (lib().vr_last_error(self._h).decode(), rc))
+
+    @property
+    def stream(self):
+        return lib().vr_stream(self._h)
+
+    def synchronize(self):
+        self._check(lib().vr_synchronize(self._h))
+
+    # --- volume (loadVolumeData, main.cpp:112-165) -------------------------------------------
+    def upload_volume(self, voxels, max_value=0.0):
+        """voxels: uint8/uint16 array [nz, ny, nx] on the host."""
+        voxels = np.ascontiguousarray(voxels)
+        if voxels.dtype not in (np.uint8, np.uint16) or voxels.ndim != 3:
+            raise TypeError("voxels must be a 3-D uint8 or uint16 array")
+        nz, ny, nx = voxels.shape
+        self._check(lib().vr_upload_volume(self._h, voxels.ctypes.data, voxels.dtype.itemsize, nx, ny, nz, max_value))
+
+    def upload_volume_device(self, ptr, dtype_bytes, nx, ny, nz, max_value=0.0):
+        self._check(lib().vr_upload_volume_device(self._h, ptr, dtype_bytes, nx, ny, nz, max_value))
+
+    def load_volume_data(self, directory):
+        self._check(lib().vr_load_volume_slices(self._h, os.fsencode(directory)))
+
+    def volume_info(self):
+        v = [C.c_int() for _ in range(4)]
+        mx = C.c_float()
+        self._check(lib().vr_volume_info(self._h, *[C.byref(x) for x in v], C.byref(mx)))
+        return {"nx": v[0].value, "ny": v[1].value, "nz": v[2].value, "dtype": v[3].value, "max_value": mx.value}
+
+    def read_volume_normalized(self):
+        i = self.volume_info()
+        out = np.empty((i["nz"], i["ny"], i["nx"]), np.float32)
+        self._check(lib().vr_read_volume_normalized(self._h, _fp(out)))
+        return out
+
+    def phantom_generate_device(self, ptr, dtype_bytes, n, seed=0x5EED1234):
+        self._check(lib().vr_phantom_generate_device(self._h, ptr, dtype_bytes, n, seed))
+
+    # --- transfer function (updateTransferFunction, main.cpp:643-686) ------------------------
+    def update_transfer_function(self, graphs, reset_state=False):
+        """graphs: four sequences (R,G,B,A) of (x, intensity) control points."""
+        keep, ptrs, counts = [], (C.POINTER(CtrlPt) * 4)(), (C.c_int * 4)()
+        for c in range(4):
+            g = list(graphs[c]) if c < len(graphs) and graphs[c] is not None else []
+            arr = (CtrlPt * max(1, len(g)))()
+            for k, (x, i) in enumerate(g):
+                arr[k].x, arr[k].intensity = float(x), float(i)
+            keep.append(arr)
+            ptrs[c] = C.cast(arr, C.POINTER(CtrlPt))
+            counts[c] = len(g)
+        self._check(lib().vr_set_transfer_function(self._h, ptrs, counts, int(bool(reset_state))))
+
+    def transfer_function(self):
+        out = np.empty((256, 4), np.float32)
+        self._check(lib().vr_get_lut(self._h, _fp(out)))
+        return out
+
+    # --- camera (setupViewPyramid / updatePixelTransformationUniforms, main.cpp:182-202, 737-799)
+    def set_camera(self, horizontal_rad, vertical_rad):
+        self._check(lib().vr_set_camera(self._h, horizontal_rad, vertical_rad))
+
+    def set_camera_raw(self, location, to_world):
+        loc = np.ascontiguousarray(location, np.float32)
+        m = np.ascontiguousarray(to_world, np.float32)
+        assert loc.size == 4 and m.size == 16
+        self._check(lib().vr_set_camera_raw(self._h, _fp(loc), _fp(m)))
+
+    def pixel_transformation_uniforms(self, width, height):
+        vp = np.empty(20, np.float32)
+        m = np.empty(16, np.float32)
+        self._check(lib().vr_get_camera(self._h, width, height, _fp(vp), _fp(m)))
+        return vp, m
+
+    def set_sampling(self, samples_per_ray, tf_border=None):
+        b = None if tf_border is None else np.ascontiguousarray(tf_border, np.float32)
+        self._check(lib().vr_set_sampling(self._h, samples_per_ray, None if b is None else _fp(b)))
+
+    def set_mode(self, mode):
+        self._check(lib().vr_set_mode(self._h, mode))
+
+    # --- frame (renderCommands' dispatch, main.cpp:823-828) -----------------------------------
+    def render(self, width, height, stats=False, rect=None):
+        x0, y0, x1, y1 = (0, 0, width, height) if rect is None else rect
+        out = np.empty((y1 - y0, x1 - x0, 4), np.uint8)
+        st = Stats() if stats else None
+        self._check(lib().vr_render_rect(self._h, width, height, x0, y0, x1, y1, out.ctypes.data, 0,
+                                         C.byref(st) if stats else None))
+        return (out, st.as_dict()) if stats else out
+
+    def render_device(self, width, height, ptr, stats=False, rect=None):
+        """Renders into device memory at `ptr`, asynchronously on the context's stream."""
+        x0, y0, x1, y1 = (0, 0, width, height) if rect is None else rect
+        st = Stats() if stats else None
+        self._check(lib().vr_render_rect(self._h, width, height, x0, y0, x1, y1, ptr, 1,
+                                         C.byref(st) if stats else None))
+        return st.as_dict() if stats else None

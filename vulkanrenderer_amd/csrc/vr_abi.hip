@@ -1,0 +1,530 @@
+// Host side of libvr_hip.so: the context object and the extern "C" entry points declared in
+// include/vr_abi.h.  Plays the part of the VolumeRendering application's initComputePipeline /
+// preRenderLoop / renderCommands / postRenderLoop (Applications/VolumeRendering/Source/main.cpp:
+// 203-573, 574-641, 800-935, 1246-1283) with HIP in place of the Vulkan objects.
+#include "../../include/vr_abi.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <filesystem>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "vr_camera.hpp"
+#include "vr_kernels.hpp"
+
+struct vr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string error;
+
+    // volume
+    void *bricks = nullptr;
+    uint32_t *cells = nullptr;
+    uint32_t *touched = nullptr;  // one bit per brick, stats only
+    size_t brick_count = 0;
+    int dtype = 0, nx = 0, ny = 0, nz = 0, nbx = 0, nby = 0, nbz = 0;
+    float max_value = 0.0f, inv_hi = 0.0f, inv_lo = 0.0f;
+
+    // transfer function
+    float *lut = nullptr;  // 256 x RGBA on the device, persists like `transferFunction`
+    vr::CtrlPt *d_pts = nullptr;
+    size_t d_pts_cap = 0;
+    float border[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+
+    // camera
+    bool raw_camera = false;
+    float h_rad = 0.0f, v_rad = 0.0f;
+    float raw_loc[4] = {0, 0, 0, 1};
+    float raw_m[16] = {0};
+
+    int samples = 200;  // VolumeRendering.comp:173
+    int mode = VR_MODE_REFERENCE_ORDER;
+
+    vr::Counters *counters = nullptr;  // device
+    uint32_t *frame = nullptr;         // device staging for host-pointer renders
+    size_t frame_cap = 0;
+};
+
+namespace {
+
+int fail(vr_ctx *ctx, int code, const std::string &msg)
+{
+    if (ctx) ctx->error = msg;
+    return code;
+}
+
+#define VR_HIP(ctx, call)                                                                              \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail((ctx), VR_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));         \
+    } while (0)
+
+int bind(vr_ctx *ctx)
+{
+    VR_HIP(ctx, hipSetDevice(ctx->device));
+    return VR_OK;
+}
+
+void release_volume(vr_ctx *ctx)
+{
+    if (ctx->bricks) (void)hipFree(ctx->bricks);
+    if (ctx->cells) (void)hipFree(ctx->cells);
+    if (ctx->touched) (void)hipFree(ctx->touched);
+    ctx->bricks = nullptr;
+    ctx->cells = nullptr;
+    ctx->touched = nullptr;
+    ctx->brick_count = 0;
+    ctx->dtype = 0;
+}
+
+vr::VolumeView view_of(const vr_ctx *ctx)
+{
+    vr::VolumeView v;
+    v.bricks = ctx->bricks;
+    v.cells = ctx->cells;
+    v.nx = ctx->nx; v.ny = ctx->ny; v.nz = ctx->nz;
+    v.nbx = ctx->nbx; v.nby = ctx->nby; v.nbz = ctx->nbz;
+    v.fx = (float)ctx->nx; v.fy = (float)ctx->ny; v.fz = (float)ctx->nz;
+    v.inv_hi = ctx->inv_hi; v.inv_lo = ctx->inv_lo;
+    v.max_value = ctx->max_value;
+    return v;
+}
+
+// Re-tiles a linear device volume into bricks.  d_raw may be modified (byte swap) when
+// big_endian is set.  Frees nothing of the caller's.
+template <typename T>
+int ingest_device(vr_ctx *ctx, T *d_raw, int nx, int ny, int nz, float max_value, bool big_endian)
+{
+    const size_t count = (size_t)nx * ny * nz;
+    uint32_t *d_max = nullptr;
+    VR_HIP(ctx, hipMalloc(&d_max, sizeof(uint32_t)));
+    VR_HIP(ctx, hipMemsetAsync(d_max, 0, sizeof(uint32_t), ctx->stream));
+    const int blocks = (int)std::min<size_t>((count + 255) / 256, 256 * 16);
+    if (big_endian)
+        hipLaunchKernelGGL((vr::k_swap_max<T, true>), dim3(blocks), dim3(256), 0, ctx->stream, d_raw, count, d_max);
+    else
+        hipLaunchKernelGGL((vr::k_swap_max<T, false>), dim3(blocks), dim3(256), 0, ctx->stream, d_raw, count, d_max);
+    uint32_t data_max = 0;
+    VR_HIP(ctx, hipMemcpyAsync(&data_max, d_max, sizeof data_max, hipMemcpyDeviceToHost, ctx->stream));
+    VR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(d_max);
+
+    float mx = (float)data_max;  // main.cpp:144, exact for 16-bit values
+    if (max_value > 0.0f) {
+        if (max_value < mx) return fail(ctx, VR_ERR_ARG, "max_value is below the data maximum");
+        mx = max_value;
+    }
+    if (!(mx > 0.0f)) return fail(ctx, VR_ERR_ARG, "volume is all zero: the reference would divide by zero");
+    if (mx > 65535.0f) return fail(ctx, VR_ERR_ARG, "max_value above 65535");
+
+    release_volume(ctx);
+    ctx->nx = nx; ctx->ny = ny; ctx->nz = nz;
+    ctx->nbx = (nx + 2 * vr::kPad + vr::kBrick - 1) / vr::kBrick;
+    ctx->nby = (ny + 2 * vr::kPad + vr::kBrick - 1) / vr::kBrick;
+    ctx->nbz = (nz + 2 * vr::kPad + vr::kBrick - 1) / vr::kBrick;
+    ctx->brick_count = (size_t)ctx->nbx * ctx->nby * ctx->nbz;
+    if (ctx->brick_count >= (1ull << 31)) return fail(ctx, VR_ERR_ARG, "volume too large");
+    ctx->dtype = (int)sizeof(T);
+    ctx->max_value = mx;
+    // v / max == fma(v, inv_hi, v * inv_lo) bit for bit for all integers 0 <= v <= max <= 65535
+    ctx->inv_hi = 1.0f / mx;
+    ctx->inv_lo = (float)(1.0 / (double)mx - (double)ctx->inv_hi);
+    VR_HIP(ctx, hipMalloc(&ctx->bricks, ctx->brick_count * vr::kBrickElems * sizeof(T)));
+    VR_HIP(ctx, hipMalloc(&ctx->cells, ctx->brick_count * sizeof(uint32_t)));
+    VR_HIP(ctx, hipMalloc(&ctx->touched, ((ctx->brick_count + 31) / 32) * sizeof(uint32_t)));
+    hipLaunchKernelGGL((vr::k_build_bricks<T>), dim3((unsigned)ctx->brick_count), dim3(256), 0, ctx->stream,
+                       (const T *)d_raw, (T *)ctx->bricks, ctx->cells, nx, ny, nz, ctx->nbx, ctx->nby);
+    VR_HIP(ctx, hipGetLastError());
+    VR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VR_OK;
+}
+
+int check_dims(vr_ctx *ctx, int dtype, int nx, int ny, int nz)
+{
+    if (dtype != VR_DTYPE_U8 && dtype != VR_DTYPE_U16) return fail(ctx, VR_ERR_ARG, "dtype must be VR_DTYPE_U8 or VR_DTYPE_U16");
+    if (nx < 1 || ny < 1 || nz < 1 || nx > 8192 || ny > 8192 || nz > 8192) return fail(ctx, VR_ERR_ARG, "volume dimensions out of range");
+    return VR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int vr_create(int device, vr_ctx **out)
+{
+    if (!out) return VR_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return VR_ERR_HIP;
+    vr_ctx *ctx = new vr_ctx();
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
+        hipMalloc(&ctx->lut, 1024 * sizeof(float)) != hipSuccess ||
+        hipMalloc(&ctx->counters, sizeof(vr::Counters)) != hipSuccess ||
+        hipMemset(ctx->lut, 0, 1024 * sizeof(float)) != hipSuccess ||  // main.cpp:110: zero-initialised table
+        hipMemset(ctx->counters, 0, sizeof(vr::Counters)) != hipSuccess ||
+        hipMemcpyToSymbol(HIP_SYMBOL(vr::d_phantom), vr::PHANTOM, sizeof(vr::PHANTOM)) != hipSuccess) {
+        vr_destroy(ctx);
+        return VR_ERR_HIP;
+    }
+    *out = ctx;
+    return VR_OK;
+}
+
+int vr_destroy(vr_ctx *ctx)
+{
+    if (!ctx) return VR_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    release_volume(ctx);
+    if (ctx->lut) (void)hipFree(ctx->lut);
+    if (ctx->d_pts) (void)hipFree(ctx->d_pts);
+    if (ctx->counters) (void)hipFree(ctx->counters);
+    if (ctx->frame) (void)hipFree(ctx->frame);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return VR_OK;
+}
+
+const char *vr_last_error(const vr_ctx *ctx) { return ctx ? ctx->error.c_str() : "null context"; }
+
+void *vr_stream(vr_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int vr_synchronize(vr_ctx *ctx)
+{
+    if (!ctx) return VR_ERR_ARG;
+    if (int rc = bind(ctx)) return rc;
+    VR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VR_OK;
+}
+
+int vr_upload_volume_device(vr_ctx *ctx, const void *d_voxels, int dtype, int nx, int ny, int nz, float max_value)
+{
+    if (!ctx || !d_voxels) return fail(ctx, VR_ERR_ARG, "null argument");
+    if (int rc = check_dims(ctx, dtype, nx, ny, nz)) return rc;
+    if (int rc = bind(ctx)) return rc;
+    if (dtype == VR_DTYPE_U8) return ingest_device<uint8_t>(ctx, (uint8_t *)d_voxels, nx, ny, nz, max_value, false);
+    return ingest_device<uint16_t>(ctx, (uint16_t *)d_voxels, nx, ny, nz, max_value, false);
+}
+
+int vr_upload_volume(vr_ctx *ctx, const void *voxels, int dtype, int nx, int ny, int nz, float max_value)
+{
+    if (!ctx || !voxels) return fail(ctx, VR_ERR_ARG, "null argument");
+    if (int rc = check_dims(ctx, dtype, nx, ny, nz)) return rc;
+    if (int rc = bind(ctx)) return rc;
+    const size_t bytes = (size_t)nx * ny * nz * (size_t)dtype;
+    void *d_raw = nullptr;
+    VR_HIP(ctx, hipMalloc(&d_raw, bytes));
+    hipError_t e = hipMemcpyAsync(d_raw, voxels, bytes, hipMemcpyHostToDevice, ctx->stream);
+    int rc = VR_OK;
+    if (e != hipSuccess) rc = fail(ctx, VR_ERR_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e));
+    if (rc == VR_OK) rc = vr_upload_volume_device(ctx, d_raw, dtype, nx, ny, nz, max_value);
+    (void)hipFree(d_raw);
+    return rc;
+}
+
+int vr_load_volume_slices(vr_ctx *ctx, const char *directory)
+{
+    if (!ctx || !directory) return fail(ctx, VR_ERR_ARG, "null argument");
+    if (int rc = bind(ctx)) return rc;
+    namespace fs = std::filesystem;
+    std::vector<std::pair<int, fs::path>> files;
+    std::error_code ec;
+    for (fs::directory_iterator it(directory, ec), end; !ec && it != end; it.increment(ec)) {
+        // main.cpp:123-128: the integer after the extension dot, or the whole file name
+        const fs::path &p = it->path();
+        std::string key = p.has_extension() ? p.extension().string().substr(1) : p.filename().string();
+        files.emplace_back(std::atoi(key.c_str()), p);
+    }
+    if (ec) return fail(ctx, VR_ERR_IO, std::string("cannot list ") + directory + ": " + ec.message());
+    if (files.empty()) return fail(ctx, VR_ERR_IO, std::string("Unavailable volume data files for loading at ") + directory);  // main.cpp:158
+    std::stable_sort(files.begin(), files.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+
+    std::vector<uint16_t> raw;
+    size_t first_count = 0;
+    for (size_t f = 0; f < files.size(); f++) {
+        std::ifstream in(files[f].second, std::ios::binary | std::ios::ate);
+        if (!in) return fail(ctx, VR_ERR_IO, "Can't open file at " + files[f].second.string());  // main.cpp:134
+        const size_t values = (size_t)in.tellg() / 2;  // a trailing odd byte is dropped, as main.cpp:138 does
+        in.seekg(0);
+        const size_t at = raw.size();
+        raw.resize(at + values);
+        in.read(reinterpret_cast<char *>(raw.data() + at), (std::streamsize)(values * 2));
+        if (f == 0) first_count = values;
+    }
+    const int side = (int)std::sqrt((double)first_count);  // main.cpp:153
+    const int slices = (int)files.size();
+    if (side < 1 || (size_t)side * side * slices != raw.size())
+        return fail(ctx, VR_ERR_IO, "slice files are not equally sized squares");
+    uint16_t *d_raw = nullptr;
+    VR_HIP(ctx, hipMalloc(&d_raw, raw.size() * 2));
+    hipError_t e = hipMemcpyAsync(d_raw, raw.data(), raw.size() * 2, hipMemcpyHostToDevice, ctx->stream);
+    int rc = VR_OK;
+    if (e != hipSuccess) rc = fail(ctx, VR_ERR_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e));
+    if (rc == VR_OK) rc = ingest_device<uint16_t>(ctx, d_raw, side, side, slices, 0.0f, true);
+    (void)hipFree(d_raw);
+    return rc;
+}
+
+int vr_volume_info(const vr_ctx *ctx, int *nx, int *ny, int *nz, int *dtype, float *max_value)
+{
+    if (!ctx) return VR_ERR_ARG;
+    if (!ctx->bricks) return VR_ERR_STATE;
+    if (nx) *nx = ctx->nx;
+    if (ny) *ny = ctx->ny;
+    if (nz) *nz = ctx->nz;
+    if (dtype) *dtype = ctx->dtype;
+    if (max_value) *max_value = ctx->max_value;
+    return VR_OK;
+}
+
+int vr_read_volume_normalized(vr_ctx *ctx, float *out)
+{
+    if (!ctx || !out) return fail(ctx, VR_ERR_ARG, "null argument");
+    if (!ctx->bricks) return fail(ctx, VR_ERR_STATE, "no volume uploaded");
+    if (int rc = bind(ctx)) return rc;
+    const size_t count = (size_t)ctx->nx * ctx->ny * ctx->nz;
+    float *d = nullptr;
+    VR_HIP(ctx, hipMalloc(&d, count * sizeof(float)));
+    const int blocks = (int)std::min<size_t>((count + 255) / 256, 256 * 16);
+    if (ctx->dtype == VR_DTYPE_U8)
+        hipLaunchKernelGGL((vr::k_read_normalized<uint8_t>), dim3(blocks), dim3(256), 0, ctx->stream, view_of(ctx), d);
+    else
+        hipLaunchKernelGGL((vr::k_read_normalized<uint16_t>), dim3(blocks), dim3(256), 0, ctx->stream, view_of(ctx), d);
+    hipError_t e = hipMemcpyAsync(out, d, count * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(ctx, VR_ERR_HIP, hipGetErrorString(e));
+    return VR_OK;
+}
+
+int vr_set_transfer_function(vr_ctx *ctx, const vr_ctrl_pt *const points[4], const int counts[4], int reset_state)
+{
+    if (!ctx || !points || !counts) return fail(ctx, VR_ERR_ARG, "null argument");
+    if (int rc = bind(ctx)) return rc;
+    std::vector<vr::CtrlPt> packed;
+    int offs[5] = {0, 0, 0, 0, 0};
+    for (int c = 0; c < 4; c++) {
+        if (counts[c] < 0 || counts[c] > 4096) return fail(ctx, VR_ERR_ARG, "control point count out of range");
+        if (counts[c] > 0 && !points[c]) return fail(ctx, VR_ERR_ARG, "null control graph");
+        for (int k = 0; k < counts[c]; k++) {
+            const vr_ctrl_pt &p = points[c][k];
+            // The reference keeps every graph sorted by x with x >= 0 (main.cpp:1009-1012, 1024);
+            // anything else indexes outside the table there.
+            if (!(p.x >= 0.0f) || !std::isfinite(p.x) || (k > 0 && p.x < points[c][k - 1].x))
+                return fail(ctx, VR_ERR_ARG, "control points must have finite x >= 0 in ascending order");
+            packed.push_back({p.x, p.intensity});
+        }
+        if (counts[c] > 0 && !(points[c][counts[c] - 1].x > 0.0f))
+            return fail(ctx, VR_ERR_ARG, "the last control point needs x > 0 (x is divided by it, main.cpp:653)");
+        offs[c + 1] = (int)packed.size();
+    }
+    if (packed.size() > ctx->d_pts_cap) {
+        if (ctx->d_pts) (void)hipFree(ctx->d_pts);
+        ctx->d_pts = nullptr;
+        ctx->d_pts_cap = 0;
+        const size_t cap = std::max<size_t>(64, packed.size() * 2);
+        VR_HIP(ctx, hipMalloc(&ctx->d_pts, cap * sizeof(vr::CtrlPt)));
+        ctx->d_pts_cap = cap;
+    }
+    if (reset_state) VR_HIP(ctx, hipMemsetAsync(ctx->lut, 0, 1024 * sizeof(float), ctx->stream));
+    if (!packed.empty()) {
+        // synchronous on purpose: `packed` lives on this stack frame
+        VR_HIP(ctx, hipMemcpyAsync(ctx->d_pts, packed.data(), packed.size() * sizeof(vr::CtrlPt), hipMemcpyHostToDevice, ctx->stream));
+        VR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        hipLaunchKernelGGL(vr::k_lut_update, dim3(1), dim3(256), 0, ctx->stream, ctx->lut, ctx->d_pts, offs[0], offs[1], offs[2],
+                           offs[3], offs[4], ctx->counters);
+        VR_HIP(ctx, hipGetLastError());
+    }
+    return VR_OK;
+}
+
+int vr_get_lut(vr_ctx *ctx, float out[1024])
+{
+    if (!ctx || !out) return fail(ctx, VR_ERR_ARG, "null argument");
+    if (int rc = bind(ctx)) return rc;
+    vr::Counters c;
+    VR_HIP(ctx, hipMemcpyAsync(out, ctx->lut, 1024 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    VR_HIP(ctx, hipMemcpyAsync(&c, ctx->counters, sizeof c, hipMemcpyDeviceToHost, ctx->stream));
+    VR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (c.lut_error) return fail(ctx, VR_ERR_ARG, "a control graph addressed a pixel outside the 256-entry table");
+    return VR_OK;
+}
+
+float vr_control_point_intensity(float y, float child_height) { return 1.0f - (y / (child_height - 1)); }  // main.cpp:952
+
+int vr_set_camera(vr_ctx *ctx, float horizontal_rad, float vertical_rad)
+{
+    if (!ctx) return VR_ERR_ARG;
+    if (!std::isfinite(horizontal_rad) || !std::isfinite(vertical_rad)) return fail(ctx, VR_ERR_ARG, "camera angles must be finite");
+    ctx->raw_camera = false;
+    ctx->h_rad = horizontal_rad;
+    ctx->v_rad = vertical_rad;
+    return VR_OK;
+}
+
+int vr_set_camera_raw(vr_ctx *ctx, const float location[4], const float to_world[16])
+{
+    if (!ctx || !location || !to_world) return fail(ctx, VR_ERR_ARG, "null argument");
+    ctx->raw_camera = true;
+    std::memcpy(ctx->raw_loc, location, sizeof ctx->raw_loc);
+    std::memcpy(ctx->raw_m, to_world, sizeof ctx->raw_m);
+    return VR_OK;
+}
+
+int vr_get_camera(vr_ctx *ctx, int width, int height, float view_pyramid[20], float to_world[16])
+{
+    if (!ctx || !view_pyramid || !to_world) return fail(ctx, VR_ERR_ARG, "null argument");
+    if (width < 2 || height < 2) return fail(ctx, VR_ERR_ARG, "image must be at least 2x2 (1/(extent-1), main.cpp:772-773)");
+    if (ctx->raw_camera) {
+        std::memset(view_pyramid, 0, 20 * sizeof(float));
+        view_pyramid[0] = vr::cam::kPyramidHeight;
+        std::memcpy(view_pyramid + 4, ctx->raw_loc, 4 * sizeof(float));
+        std::memcpy(to_world, ctx->raw_m, 16 * sizeof(float));
+        return VR_OK;
+    }
+    vr::cam::pixel_transform(ctx->h_rad, ctx->v_rad, (uint32_t)width, (uint32_t)height, view_pyramid, to_world);
+    return VR_OK;
+}
+
+int vr_camera_uniforms(float horizontal_rad, float vertical_rad, int width, int height, float view_pyramid[20],
+                       float to_world[16])
+{
+    if (!view_pyramid || !to_world || width < 2 || height < 2) return VR_ERR_ARG;
+    vr::cam::pixel_transform(horizontal_rad, vertical_rad, (uint32_t)width, (uint32_t)height, view_pyramid, to_world);
+    return VR_OK;
+}
+
+int vr_set_sampling(vr_ctx *ctx, int samples_per_ray, const float tf_border_rgba[4])
+{
+    if (!ctx) return VR_ERR_ARG;
+    if (samples_per_ray < 0 || samples_per_ray > (1 << 20)) return fail(ctx, VR_ERR_ARG, "samples_per_ray out of range");
+    ctx->samples = samples_per_ray;
+    if (tf_border_rgba) std::memcpy(ctx->border, tf_border_rgba, sizeof ctx->border);
+    return VR_OK;
+}
+
+int vr_set_mode(vr_ctx *ctx, int mode)
+{
+    if (!ctx) return VR_ERR_ARG;
+    if (mode != VR_MODE_REFERENCE_ORDER && mode != VR_MODE_FAST) return fail(ctx, VR_ERR_ARG, "unknown mode");
+    ctx->mode = mode;
+    return VR_OK;
+}
+
+int vr_render_rect(vr_ctx *ctx, int width, int height, int x0, int y0, int x1, int y1, uint8_t *out, int out_is_device,
+                   vr_stats *stats)
+{
+    if (!ctx || !out) return fail(ctx, VR_ERR_ARG, "null argument");
+    if (!ctx->bricks) return fail(ctx, VR_ERR_STATE, "no volume uploaded");
+    if (width < 2 || height < 2 || width > 65536 || height > 65536) return fail(ctx, VR_ERR_ARG, "image size out of range");
+    if (x0 < 0 || y0 < 0 || x1 > width || y1 > height || x0 >= x1 || y0 >= y1) return fail(ctx, VR_ERR_ARG, "bad pixel rectangle");
+    if (int rc = bind(ctx)) return rc;
+
+    vr::FrameParams fp;
+    float pyramid[20];
+    if (int rc = vr_get_camera(ctx, width, height, pyramid, fp.m)) return rc;
+    std::memcpy(fp.loc, pyramid + 4, sizeof fp.loc);
+    fp.width = width; fp.height = height;
+    fp.x0 = x0; fp.y0 = y0; fp.x1 = x1; fp.y1 = y1;
+    fp.samples = ctx->samples;
+    fp.pad_ = 0;
+
+    const size_t pixels = (size_t)(x1 - x0) * (y1 - y0);
+    uint32_t *d_out = reinterpret_cast<uint32_t *>(out);
+    if (!out_is_device) {
+        if (pixels > ctx->frame_cap) {
+            if (ctx->frame) (void)hipFree(ctx->frame);
+            ctx->frame = nullptr;
+            ctx->frame_cap = 0;
+            VR_HIP(ctx, hipMalloc(&ctx->frame, pixels * 4));
+            ctx->frame_cap = pixels;
+        }
+        d_out = ctx->frame;
+    }
+    const bool want_stats = stats != nullptr;
+    if (want_stats) {
+        VR_HIP(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(vr::Counters), ctx->stream));
+        VR_HIP(ctx, hipMemsetAsync(ctx->touched, 0, ((ctx->brick_count + 31) / 32) * sizeof(uint32_t), ctx->stream));
+    }
+    const int tiles_x = (x1 - x0 + 15) / 16, tiles_y = (y1 - y0 + 15) / 16;
+    const dim3 grid((unsigned)(tiles_x * tiles_y)), block(256);
+    const vr::VolumeView vol = view_of(ctx);
+    const float4 border = make_float4(ctx->border[0], ctx->border[1], ctx->border[2], ctx->border[3]);
+    const float4 *lut = reinterpret_cast<const float4 *>(ctx->lut);
+
+    VR_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    if (ctx->dtype == VR_DTYPE_U8) {
+        if (want_stats)
+            hipLaunchKernelGGL((vr::k_march_reference<uint8_t, true>), grid, block, 0, ctx->stream, vol, fp, lut, border, d_out, ctx->counters, ctx->touched);
+        else
+            hipLaunchKernelGGL((vr::k_march_reference<uint8_t, false>), grid, block, 0, ctx->stream, vol, fp, lut, border, d_out, ctx->counters, ctx->touched);
+    } else {
+        if (want_stats)
+            hipLaunchKernelGGL((vr::k_march_reference<uint16_t, true>), grid, block, 0, ctx->stream, vol, fp, lut, border, d_out, ctx->counters, ctx->touched);
+        else
+            hipLaunchKernelGGL((vr::k_march_reference<uint16_t, false>), grid, block, 0, ctx->stream, vol, fp, lut, border, d_out, ctx->counters, ctx->touched);
+    }
+    VR_HIP(ctx, hipGetLastError());
+    VR_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+
+    if (!out_is_device) {
+        VR_HIP(ctx, hipMemcpyAsync(out, d_out, pixels * 4, hipMemcpyDeviceToHost, ctx->stream));
+        VR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (want_stats) {
+        vr::Counters c;
+        VR_HIP(ctx, hipMemcpyAsync(&c, ctx->counters, sizeof c, hipMemcpyDeviceToHost, ctx->stream));
+        std::vector<uint32_t> bits((ctx->brick_count + 31) / 32);
+        VR_HIP(ctx, hipMemcpyAsync(bits.data(), ctx->touched, bits.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        VR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        uint64_t touched = 0;
+        for (uint32_t w : bits) touched += (uint64_t)__builtin_popcount(w);
+        std::memset(stats, 0, sizeof *stats);
+        stats->rays = pixels;
+        stats->rays_hit = c.rays_hit;
+        stats->samples_nominal = c.rays_hit * (uint64_t)(ctx->samples + 2);
+        stats->samples_evaluated = c.samples_evaluated;
+        stats->cells_read = c.cells_read;
+        stats->bricks_touched = touched;
+        stats->replay_rays = c.replay_rays;
+        const uint64_t brick_bytes = (uint64_t)vr::kBrick * vr::kBrick * vr::kBrick * (uint64_t)ctx->dtype;
+        stats->algorithmic_bytes = brick_bytes * touched + 4ull * touched + (uint64_t)vr::kLutLds * 16ull + 4ull * pixels;
+        float ms = 0.0f;
+        VR_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+        stats->kernel_ms = ms;
+    }
+    return VR_OK;
+}
+
+int vr_render(vr_ctx *ctx, int width, int height, uint8_t *out, int out_is_device, vr_stats *stats)
+{
+    return vr_render_rect(ctx, width, height, 0, 0, width, height, out, out_is_device, stats);
+}
+
+int vr_phantom_generate_device(vr_ctx *ctx, void *d_out, int dtype, int n, uint32_t seed)
+{
+    if (!ctx || !d_out) return fail(ctx, VR_ERR_ARG, "null argument");
+    if (int rc = check_dims(ctx, dtype, n, n, n)) return rc;
+    if (int rc = bind(ctx)) return rc;
+    const size_t count = (size_t)n * n * n;
+    const int blocks = (int)std::min<size_t>((count + 255) / 256, 256 * 32);
+    if (dtype == VR_DTYPE_U8)
+        hipLaunchKernelGGL((vr::k_phantom<uint8_t>), dim3(blocks), dim3(256), 0, ctx->stream, (uint8_t *)d_out, (uint32_t)n, 255u, seed);
+    else
+        hipLaunchKernelGGL((vr::k_phantom<uint16_t>), dim3(blocks), dim3(256), 0, ctx->stream, (uint16_t *)d_out, (uint32_t)n, 65535u, seed);
+    VR_HIP(ctx, hipGetLastError());
+    return VR_OK;
+}
+
+}  // extern "C"

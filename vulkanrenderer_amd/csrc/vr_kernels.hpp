@@ -1,0 +1,471 @@
+// gfx950 kernels of the volume-rendering core.  Wave = 64 lanes; one lane marches one ray and a
+// wave owns an 8x8 pixel tile, so neighbouring lanes walk neighbouring voxels.
+//
+// Every float expression that decides a sample value is written so that it rounds exactly like
+// the shader it replaces (Applications/VolumeRendering/Shader/VolumeRendering.comp) evaluated
+// with one rounding per operation; the file must be compiled with -ffp-contract=off and the
+// only fused operations are the explicit __builtin_fmaf calls (texture-filter lerps and the
+// exact u16/max quotient).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vr {
+
+// ---- volume layout ------------------------------------------------------------------------
+// Voxel index i of an axis is stored at padded coordinate s = i + 2, so that the border texels
+// -1 and size (and one more on each side, reached only through rounding) are ordinary zeros.
+// The padded grid is cut into 8^3 bricks; a brick stores the 9^3 voxels s in [8b, 8b+8] of each
+// axis (its own 8^3 plus a one-voxel apron), so the 8 corners of any trilinear footprint whose
+// low corner lies in the brick come from that one brick.  Row pitch 9, slice pitch 81, brick
+// pitch 768 elements (729 used; 1536 B for u16 keeps bricks 128-byte aligned).
+constexpr int kBrick = 8;
+constexpr int kRow = 9;
+constexpr int kSlice = 81;
+constexpr int kBrickElems = 768;
+constexpr int kPad = 2;
+
+struct VolumeView {
+    const void *bricks;
+    const uint32_t *cells;  // per brick: min | max << 16 over its 9^3 stored voxels
+    int nx, ny, nz;         // voxels
+    int nbx, nby, nbz;      // bricks
+    float fx, fy, fz;       // (float) nx, ny, nz
+    float inv_hi, inv_lo;   // 1/max split in two floats: v/max == fma(v, inv_hi, v*inv_lo) exactly
+    float max_value;
+};
+
+struct FrameParams {
+    float m[16];      // toWorld, column-major (VolumeRendering.comp:20-22)
+    float loc[4];     // viewPyramid.location (VolumeRendering.comp:14)
+    int width, height;
+    int x0, y0, x1, y1;  // pixel rectangle to render
+    int samples;         // shader constant `samples` (VolumeRendering.comp:173)
+    int pad_;
+};
+
+struct Counters {
+    unsigned long long rays_hit;
+    unsigned long long samples_evaluated;
+    unsigned long long cells_read;
+    unsigned long long replay_rays;
+    unsigned int replay_count;  // queue fill of the fast mode
+    unsigned int lut_error;
+};
+
+// LDS image of the transfer function: [0],[1] border, [2..257] the 256 texels, [258],[259] border.
+constexpr int kLutLds = 260;
+
+__device__ __forceinline__ float glsl_min(float x, float y) { return y < x ? y : x; }
+__device__ __forceinline__ float glsl_max(float x, float y) { return x < y ? y : x; }
+__device__ __forceinline__ float lerp_fma(float w, float a, float b) { return __builtin_fmaf(w, b - a, a); }
+
+// floor()ed coordinate -> int, defined for any input: below -2 behaves like -2 and above size
+// like size (both neighbours are border texels either way); NaN behaves like -2.
+__device__ __forceinline__ int safe_index(float fl, int size)
+{
+    if (!(fl >= -2.0f)) fl = -2.0f;
+    if (fl > (float)size) fl = (float)size;
+    return (int)fl;
+}
+
+template <typename T>
+struct Voxel;
+template <>
+struct Voxel<uint16_t> {
+    // two neighbouring voxels of a brick row with one (possibly unaligned) 4-byte load
+    static __device__ __forceinline__ void pair(const uint16_t *p, float &a, float &b)
+    {
+        uint32_t w;
+        __builtin_memcpy(&w, p, 4);
+        a = (float)(w & 0xffffu);
+        b = (float)(w >> 16);
+    }
+};
+template <>
+struct Voxel<uint8_t> {
+    static __device__ __forceinline__ void pair(const uint8_t *p, float &a, float &b)
+    {
+        uint16_t w;
+        __builtin_memcpy(&w, p, 2);
+        a = (float)(w & 0xffu);
+        b = (float)(w >> 8);
+    }
+};
+
+struct Ray {
+    float o[3], d[3];
+    float tmin, tmax;
+    bool hit;
+};
+
+// Ray generation and slab test: VolumeRendering.comp:159-160, 177-178, 50-96.
+__device__ __forceinline__ Ray make_ray(const FrameParams &fp, int px, int py)
+{
+    Ray r;
+    const float fx = (float)px, fy = (float)py;
+    float d[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float t = fp.m[4 + c] * fy + fp.m[12 + c];
+        const float world = fp.m[c] * fx + t;
+        d[c] = world - fp.loc[c];
+        r.o[c] = fp.loc[c];
+    }
+    const float inv = 1.0f / sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+#pragma unroll
+    for (int c = 0; c < 3; c++) r.d[c] = d[c] * inv;
+    float t1 = (-0.5f - r.o[0]) / r.d[0], t2 = (0.5f - r.o[0]) / r.d[0];
+    const float tminx = glsl_min(t1, t2), tmaxx = glsl_max(t1, t2);
+    t1 = (-0.5f - r.o[1]) / r.d[1];
+    t2 = (0.5f - r.o[1]) / r.d[1];
+    const float tminy = glsl_min(t1, t2), tmaxy = glsl_max(t1, t2);
+    t1 = (-1.0f - r.o[2]) / r.d[2];
+    t2 = (0.0f - r.o[2]) / r.d[2];
+    const float tminz = glsl_min(t1, t2), tmaxz = glsl_max(t1, t2);
+    r.tmin = glsl_max(glsl_max(tminx, tminy), tminz);
+    r.tmax = glsl_min(glsl_min(tmaxx, tmaxy), tmaxz);
+    r.hit = !(r.tmin > r.tmax || r.tmax < 0.0f);
+    return r;
+}
+
+// Position of tap t in unnormalised, padded texel space (continuous coordinate whose floor is
+// the padded index of the low corner): VolumeRendering.comp:185-187 then u*size - 0.5.
+struct Tap {
+    float x, y, z;     // u*size - 0.5 per axis
+};
+
+__device__ __forceinline__ Tap tap_position(const Ray &r, const VolumeView &v, float step, int t)
+{
+    const float len = r.tmax - (float)t * step;
+    const float wx = r.o[0] + len * r.d[0];
+    const float wy = r.o[1] + len * r.d[1];
+    const float wz = r.o[2] + len * r.d[2];
+    Tap p;
+    p.x = fabsf(wx - -0.5f) * v.fx - 0.5f;
+    p.y = fabsf(wy - -0.5f) * v.fy - 0.5f;
+    p.z = fabsf(wz - 0.0f) * v.fz - 0.5f;
+    return p;
+}
+
+struct Cell {
+    int sx, sy, sz;       // padded index of the low corner, each in [0, size + 2]
+    float wx, wy, wz;     // filter weights
+};
+
+__device__ __forceinline__ Cell tap_cell(const Tap &p, const VolumeView &v)
+{
+    const float xf = floorf(p.x), yf = floorf(p.y), zf = floorf(p.z);
+    Cell c;
+    c.wx = p.x - xf;
+    c.wy = p.y - yf;
+    c.wz = p.z - zf;
+    c.sx = safe_index(xf, v.nx) + kPad;
+    c.sy = safe_index(yf, v.ny) + kPad;
+    c.sz = safe_index(zf, v.nz) + kPad;
+    return c;
+}
+
+__device__ __forceinline__ uint32_t brick_of(const Cell &c, const VolumeView &v)
+{
+    return (uint32_t)(((c.sz >> 3) * v.nby + (c.sy >> 3)) * v.nbx + (c.sx >> 3));
+}
+
+// texture(volumeTexture, tc).x with linear filtering and clamp-to-border (border .r = 0):
+// VolumeRendering.comp:187-188, sampler main.cpp:365-382.
+template <typename T>
+__device__ __forceinline__ float sample_volume(const Cell &c, uint32_t brick, const VolumeView &v)
+{
+    const T *base = (const T *)v.bricks + (size_t)brick * kBrickElems +
+                    (((c.sz & 7) * kRow + (c.sy & 7)) * kRow + (c.sx & 7));
+    float r000, r100, r010, r110, r001, r101, r011, r111;
+    Voxel<T>::pair(base, r000, r100);
+    Voxel<T>::pair(base + kRow, r010, r110);
+    Voxel<T>::pair(base + kSlice, r001, r101);
+    Voxel<T>::pair(base + kSlice + kRow, r011, r111);
+    const float hi = v.inv_hi, lo = v.inv_lo;
+    const float c000 = __builtin_fmaf(r000, hi, r000 * lo), c100 = __builtin_fmaf(r100, hi, r100 * lo);
+    const float c010 = __builtin_fmaf(r010, hi, r010 * lo), c110 = __builtin_fmaf(r110, hi, r110 * lo);
+    const float c001 = __builtin_fmaf(r001, hi, r001 * lo), c101 = __builtin_fmaf(r101, hi, r101 * lo);
+    const float c011 = __builtin_fmaf(r011, hi, r011 * lo), c111 = __builtin_fmaf(r111, hi, r111 * lo);
+    const float p0 = lerp_fma(c.wy, lerp_fma(c.wx, c000, c100), lerp_fma(c.wx, c010, c110));
+    const float p1 = lerp_fma(c.wy, lerp_fma(c.wx, c001, c101), lerp_fma(c.wx, c011, c111));
+    return lerp_fma(c.wz, p0, p1);
+}
+
+// texture(transferSampler, intensity): VolumeRendering.comp:98-106.
+__device__ __forceinline__ float4 sample_tf(const float4 *s_lut, float intensity)
+{
+    const float x = intensity * 256.0f - 0.5f;
+    const float xf = floorf(x);
+    const float w = x - xf;
+    const int i = safe_index(xf, 256) + 2;
+    const float4 a = s_lut[i], b = s_lut[i + 1];
+    return make_float4(lerp_fma(w, a.x, b.x), lerp_fma(w, a.y, b.y), lerp_fma(w, a.z, b.z), lerp_fma(w, a.w, b.w));
+}
+
+__device__ __forceinline__ uint32_t to_unorm8(float x)
+{
+    if (!(x > 0.0f)) return 0u;
+    if (x >= 1.0f) return 255u;
+    return (uint32_t)__float2int_rn(x * 255.0f);
+}
+
+__device__ __forceinline__ uint32_t pack_rgba8(float r, float g, float b)
+{
+    return to_unorm8(r) | (to_unorm8(g) << 8) | (to_unorm8(b) << 16) | 0xff000000u;
+}
+
+__device__ __forceinline__ void stage_lut(float4 *s_lut, const float4 *lut, const float4 border)
+{
+    for (int i = threadIdx.x; i < kLutLds; i += blockDim.x) {
+        float4 v = border;
+        if (i >= 2 && i < 258) v = lut[i - 2];
+        s_lut[i] = v;
+    }
+    __syncthreads();
+}
+
+// Pixel owned by a lane: a block of 256 threads covers 16x16 pixels, wave w the 8x8 tile
+// (w & 1, w >> 1), lane l the pixel (l & 7, l >> 3) of it.
+__device__ __forceinline__ void lane_pixel(const FrameParams &fp, int &px, int &py)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tiles_x = (fp.x1 - fp.x0 + 15) >> 4;
+    const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+    px = fp.x0 + bx * 16 + (wave & 1) * 8 + (lane & 7);
+    py = fp.y0 + by * 16 + (wave >> 1) * 8 + (lane >> 3);
+}
+
+// ---- reference-order march -------------------------------------------------------------------
+// Back to front over all samples + 2 taps exactly as the shader loops (VolumeRendering.comp:
+// 183-202).  With SKIP, a tap whose brick has a (min,max) range over which the transfer
+// function's alpha is exactly zero is not fetched: such a tap leaves the colour unchanged bit for
+// bit (0*c + 1*C), the back-most tap (t == 0) excepted, which is never skipped because the shader
+// assigns there instead of blending.
+template <typename T, bool STATS>
+__global__ __launch_bounds__(256) void k_march_reference(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
+                                                        float4 border, uint32_t *__restrict__ out,
+                                                        Counters *ctr, uint32_t *touched)
+{
+    __shared__ float4 s_lut[kLutLds];
+    stage_lut(s_lut, lut, border);
+    int px, py;
+    lane_pixel(fp, px, py);
+    if (px >= fp.x1 || py >= fp.y1) return;
+
+    const Ray r = make_ray(fp, px, py);
+    float cr = 0.0f, cg = 0.0f, cb = 0.0f;
+    unsigned long long evaluated = 0;
+    if (r.hit) {
+        const int last = fp.samples + 1;
+        const float step = (r.tmax - r.tmin) / (float)(uint32_t)last;
+        for (int t = 0; t <= last; t++) {
+            const Tap p = tap_position(r, vol, step, t);
+            const Cell c = tap_cell(p, vol);
+            const uint32_t brick = brick_of(c, vol);
+            const float inten = sample_volume<T>(c, brick, vol);
+            const float4 tf = sample_tf(s_lut, inten);
+            if (t == 0) {
+                cr = tf.x; cg = tf.y; cb = tf.z;
+            } else {
+                const float a = tf.w, ia = 1.0f - tf.w;
+                cr = a * tf.x + ia * cr;
+                cg = a * tf.y + ia * cg;
+                cb = a * tf.z + ia * cb;
+            }
+            if (STATS) {
+                evaluated++;
+                atomicOr(&touched[brick >> 5], 1u << (brick & 31));
+            }
+        }
+    }
+    out[(size_t)(py - fp.y0) * (fp.x1 - fp.x0) + (px - fp.x0)] = pack_rgba8(cr, cg, cb);
+    if (STATS) {
+        atomicAdd(&ctr->rays_hit, r.hit ? 1ull : 0ull);
+        atomicAdd(&ctr->samples_evaluated, evaluated);
+    }
+}
+
+// ---- transfer function table ---------------------------------------------------------------
+// updateTransferFunction, Applications/VolumeRendering/Source/main.cpp:643-686, one wave per
+// channel.  Segments are applied in order (a later segment overwrites the pixel it shares with
+// the previous one, main.cpp:660-681); inside a segment the written pixels are distinct, so the
+// lanes of a wave can take one k each.  Table entries no segment covers keep their old value.
+struct CtrlPt {
+    float x, intensity;
+};
+
+__global__ __launch_bounds__(256) void k_lut_update(float *__restrict__ lut, const CtrlPt *__restrict__ pts,
+                                                   int off0, int off1, int off2, int off3, int off4, Counters *ctr)
+{
+    __shared__ float s_chan[4][256];
+    const int lane = threadIdx.x & 63, ch = threadIdx.x >> 6;
+    const int offs[5] = {off0, off1, off2, off3, off4};
+    const int begin = offs[ch], cnt = offs[ch + 1] - offs[ch];
+    for (int i = lane; i < 256; i += 64) s_chan[ch][i] = lut[i * 4 + ch];
+    if (cnt >= 1) {
+        const CtrlPt *g = pts + begin;
+        const float x_last = g[cnt - 1].x;
+        for (int j = 1; j < cnt; j++) {
+            const float xa = (g[j - 1].x / x_last) * 255.0f;
+            const float xb = (g[j].x / x_last) * 255.0f;
+            const float dir = g[j].intensity - g[j - 1].intensity;
+            const float total = xb - xa + 1.0f;
+            uint32_t count = 0;
+            if (total >= 1.0f) count = total >= 4294967296.0f ? 0xFFFFFFFFu : (uint32_t)total;
+            if (count > 1024u) {  // cannot happen for sorted points; keeps the loop bounded
+                if (lane == 0) atomicOr(&ctr->lut_error, 1u);
+                count = 0;
+            }
+            for (uint32_t k0 = 0; k0 < count; k0 += 64) {
+                const uint32_t k = k0 + lane;
+                if (k < count) {
+                    const float val = g[j - 1].intensity + dir * ((float)k / (total - 1.0f));
+                    const float pixel = xa + (float)k;
+                    if (pixel >= 0.0f && pixel < 256.0f) s_chan[ch][(int)pixel] = val;
+                    else atomicOr(&ctr->lut_error, 1u);
+                }
+            }
+        }
+    }
+    for (int i = lane; i < 256; i += 64) lut[i * 4 + ch] = s_chan[ch][i];
+}
+
+// ---- ingest --------------------------------------------------------------------------------
+// Maximum of the raw voxels (loadVolumeData tracks it while reading, main.cpp:144); for
+// big-endian input the bytes are swapped in place first (main.cpp:141-143).
+template <typename T, bool SWAP>
+__global__ __launch_bounds__(256) void k_swap_max(T *__restrict__ raw, size_t count, uint32_t *result)
+{
+    uint32_t mx = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t v = raw[i];
+        if (SWAP) {
+            v = ((v >> 8) | (v << 8)) & 0xffffu;
+            raw[i] = (T)v;
+        }
+        mx = v > mx ? v : mx;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t other = __shfl_xor(mx, o);
+        mx = other > mx ? other : mx;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(result, mx);
+}
+
+// Re-tiles the linear volume (x fastest, then y, then slice: main.cpp:41,131-146) into bricks and
+// builds the (min,max) macrocell of each brick.  One block per brick.
+template <typename T>
+__global__ __launch_bounds__(256) void k_build_bricks(const T *__restrict__ raw, T *__restrict__ bricks,
+                                                     uint32_t *__restrict__ cells, int nx, int ny, int nz,
+                                                     int nbx, int nby)
+{
+    const uint32_t brick = blockIdx.x;
+    const int bx = brick % nbx, by = (brick / nbx) % nby, bz = brick / (nbx * nby);
+    T *dst = bricks + (size_t)brick * kBrickElems;
+    uint32_t mn = 0xffffffffu, mx = 0;
+    for (int e = threadIdx.x; e < kBrickElems; e += 256) {
+        uint32_t v = 0;
+        if (e < kRow * kRow * kRow) {
+            const int lx = e % kRow, ly = (e / kRow) % kRow, lz = e / kSlice;
+            const int ix = bx * kBrick + lx - kPad, iy = by * kBrick + ly - kPad, iz = bz * kBrick + lz - kPad;
+            if ((unsigned)ix < (unsigned)nx && (unsigned)iy < (unsigned)ny && (unsigned)iz < (unsigned)nz)
+                v = raw[((size_t)iz * ny + iy) * nx + ix];
+            mn = v < mn ? v : mn;
+            mx = v > mx ? v : mx;
+        }
+        dst[e] = (T)v;
+    }
+    __shared__ uint32_t s_mn[4], s_mx[4];
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t a = __shfl_xor(mn, o), b = __shfl_xor(mx, o);
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_mn[threadIdx.x >> 6] = mn;
+        s_mx[threadIdx.x >> 6] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) {
+            mn = s_mn[w] < mn ? s_mn[w] : mn;
+            mx = s_mx[w] > mx ? s_mx[w] : mx;
+        }
+        cells[brick] = mn | (mx << 16);
+    }
+}
+
+// float(v) / float(max) for every voxel, back in linear order: what the reference keeps in
+// `intensities` after main.cpp:161-164.  Uses the same two-term reciprocal as the sampler.
+template <typename T>
+__global__ __launch_bounds__(256) void k_read_normalized(VolumeView vol, float *__restrict__ out)
+{
+    const size_t count = (size_t)vol.nx * vol.ny * vol.nz;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        const int ix = (int)(i % vol.nx), iy = (int)((i / vol.nx) % vol.ny), iz = (int)(i / ((size_t)vol.nx * vol.ny));
+        const int sx = ix + kPad, sy = iy + kPad, sz = iz + kPad;
+        const size_t brick = ((size_t)(sz >> 3) * vol.nby + (sy >> 3)) * vol.nbx + (sx >> 3);
+        const T raw = ((const T *)vol.bricks)[brick * kBrickElems + (((sz & 7) * kRow + (sy & 7)) * kRow + (sx & 7))];
+        const float f = (float)raw;
+        out[i] = __builtin_fmaf(f, vol.inv_hi, f * vol.inv_lo);
+    }
+}
+
+// ---- synthetic phantom ------------------------------------------------------------------------
+// 3-D Shepp-Logan head (ten ellipsoids, contrast in tenths so the sum is an exact integer),
+// voxel centres of [-1,1]^3, small hash noise inside the outer ellipsoid, exactly 0 outside it.
+struct ellipsoid {
+    int tenths;
+    float ia2, ib2, ic2, x0, y0, z0, cp, sp;
+};
+#include "phantom_table.inc"
+__constant__ ellipsoid d_phantom[10];
+
+__device__ __forceinline__ uint32_t phantom_hash(uint32_t seed, uint64_t idx)
+{
+    uint32_t x = (uint32_t)idx ^ ((uint32_t)(idx >> 32) * 0x85EBCA6Bu) ^ seed;
+    x *= 0x9E3779B1u;
+    x ^= x << 13;
+    x ^= x >> 17;
+    x ^= x << 5;
+    return x >> 8;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_phantom(T *__restrict__ out, uint32_t n, uint32_t dmax, uint32_t seed)
+{
+    const uint64_t count = (uint64_t)n * n * n;
+    const float fn = (float)n;
+    const uint32_t range = (dmax + 1) / 128;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t ix = (uint32_t)(i % n), iy = (uint32_t)((i / n) % n), iz = (uint32_t)(i / ((uint64_t)n * n));
+        const float x = (float)(2 * ix + 1) / fn - 1.0f;
+        const float y = (float)(2 * iy + 1) / fn - 1.0f;
+        const float z = (float)(2 * iz + 1) / fn - 1.0f;
+        int tenths = 0;
+        bool inside_outer = false;
+#pragma unroll
+        for (int e = 0; e < 10; e++) {
+            const ellipsoid E = d_phantom[e];
+            const float dx = x - E.x0, dy = y - E.y0, dz = z - E.z0;
+            const float xr = dx * E.cp + dy * E.sp;
+            const float yr = dy * E.cp - dx * E.sp;
+            const float q = ((xr * xr) * E.ia2 + (yr * yr) * E.ib2) + (dz * dz) * E.ic2;
+            if (q <= 1.0f) {
+                tenths += E.tenths;
+                if (e == 0) inside_outer = true;
+            }
+        }
+        uint32_t v = 0;
+        if (inside_outer) {
+            tenths = tenths < 0 ? 0 : (tenths > 10 ? 10 : tenths);
+            v = (uint32_t)tenths * (dmax - (range - 1)) / 10 + phantom_hash(seed, i) % range;
+        }
+        out[i] = (T)v;
+    }
+}
+
+}  // namespace vr
