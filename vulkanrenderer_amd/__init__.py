@@ -56,6 +56,13 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError("libvr_hip.so is not built: run `make -C vulkanrenderer_amd/csrc` "
                           "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    # PyTorch-ROCm bundles its own HIP runtime under the same SONAME as /opt/rocm's.  A process
+    # must hold exactly one: load torch's first so that device memory, streams and RCCL handed
+    # over by torch.distributed code live in the runtime this library launches its kernels on.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, fp = C.c_void_p, C.POINTER(C.c_float)
     L.vr_create.argtypes = [C.c_int, C.POINTER(vp)]
