@@ -34,6 +34,7 @@ extern "C" {
 /* Render strategies.  Both produce the frame the reference shader defines. */
 #define VR_MODE_REFERENCE_ORDER 0 /* back-to-front, every tap (VolumeRendering.comp:183-202) */
 #define VR_MODE_FAST 1            /* front-to-back, macrocell skipping, early termination */
+#define VR_MODE_REFERENCE_SKIP 2  /* back-to-front, taps in exactly transparent bricks not fetched */
 
 typedef struct vr_ctx vr_ctx;
 
@@ -124,6 +125,10 @@ int vr_render(vr_ctx *ctx, int width, int height, uint8_t *out, int out_is_devic
  * (x1-x0)*(y1-y0)*4 bytes, rectangle rows contiguous.  For sort-first tiling. */
 int vr_render_rect(vr_ctx *ctx, int width, int height, int x0, int y0, int x1, int y1,
                    uint8_t *out, int out_is_device, vr_stats *stats);
+
+/* Number of rays of the rectangle that hit the volume box; the reference marches
+ * samples_per_ray + 2 taps on each of them (VolumeRendering.comp:180-184). */
+int vr_count_hit_rays(vr_ctx *ctx, int width, int height, int x0, int y0, int x1, int y1, uint64_t *hits);
 
 /* Synthetic CT phantom used as measurement input (no counterpart in the reference): n^3 voxels
  * written to device memory, then usable with vr_upload_volume_device.  d_out: n^3 * dtype bytes. */

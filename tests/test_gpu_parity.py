@@ -186,7 +186,7 @@ def render_pair(ctx, oracle, vox, graphs, cam, w, h, samples, border=(0, 0, 0, 0
     return got, want
 
 
-@pytest.mark.parametrize("mode", [0])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 def test_golden_frames(ctx, oracle, golden, mode):
     for dtype, n, tag in ((np.uint8, 32, "u8_32"), (np.uint16, 64, "u16_64")):
         ctx.upload_volume(oracle.phantom(n, dtype))
@@ -198,14 +198,14 @@ def test_golden_frames(ctx, oracle, golden, mode):
             check_frame(ctx.render(64, 64), golden["frame_%s_%s" % (tag, cname)], "golden %s %s mode %d" % (tag, cname, mode))
 
 
-@pytest.mark.parametrize("mode", [0])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("w,h", [(50, 37), (129, 65), (16, 16)])
 def test_ragged_image_sizes(ctx, oracle, mode, w, h):
     got, want = render_pair(ctx, oracle, oracle.phantom(24, np.uint16), cf.TF_GRAPHS, cf.CAMERAS["h30_v20"], w, h, 60, mode=mode)
     check_frame(got, want, "ragged %dx%d" % (w, h))
 
 
-@pytest.mark.parametrize("mode", [0])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 def test_non_cubic_volume_and_border_colour(ctx, oracle, mode):
     rng = np.random.default_rng(9)
     vox = rng.integers(0, 3000, size=(11, 33, 20)).astype(np.uint16)      # nz, ny, nx all different
@@ -214,7 +214,7 @@ def test_non_cubic_volume_and_border_colour(ctx, oracle, mode):
         check_frame(got, want, "noise volume border %s" % (border,))
 
 
-@pytest.mark.parametrize("mode", [0])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 def test_config1_full_size(ctx, oracle, mode):
     # BASELINE configs[0]: 256^3 uint8 phantom, 512x512, fixed camera (30, 20 degrees), 4-point TF, 200 samples
     got, want = render_pair(ctx, oracle, oracle.phantom(256, np.uint8), cf.TF_GRAPHS, cf.CAMERAS["h30_v20"], 512, 512, 200,
@@ -229,7 +229,7 @@ def test_config1_full_size(ctx, oracle, mode):
     assert 0 < st["bricks_touched"] <= 33 ** 3 and st["algorithmic_bytes"] > 512 * 512 * 4
 
 
-@pytest.mark.parametrize("mode", [0])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 def test_rect_equals_crop_of_frame(ctx, oracle, mode):
     ctx.upload_volume(oracle.phantom(32, np.uint8))
     ctx.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
@@ -242,7 +242,7 @@ def test_rect_equals_crop_of_frame(ctx, oracle, mode):
         assert np.array_equal(ctx.render(100, 70, rect=rect), full[y0:y1, x0:x1]), rect
 
 
-@pytest.mark.parametrize("mode", [0])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 def test_camera_inside_the_box(ctx, oracle, mode):
     # tMin < 0 is used as is (VolumeRendering.comp:93-95): taps behind the apex are still taken
     vox = oracle.phantom(32, np.uint16)
@@ -294,3 +294,64 @@ def test_call_order_and_argument_errors(vr):
             c.set_mode(7)
     h = vr.C.c_void_p()
     assert vr.lib().vr_create(9999, vr.C.byref(h)) != 0
+
+
+# ---- fast mode specifics -----------------------------------------------------------------------
+
+def test_fast_mode_skips_and_terminates(ctx, oracle):
+    vox = oracle.phantom(128, np.uint16)
+    got, want = render_pair(ctx, oracle, vox, cf.TF_GRAPHS, cf.CAMERAS["h30_v20"], 256, 256, 443, mode=1, stats=True)
+    img, st = got
+    check_frame(img, want, "fast 128^3")
+    print(st)
+    assert st["samples_nominal"] == st["rays_hit"] * 445
+    assert st["samples_evaluated"] < 0.25 * st["samples_nominal"]      # skipping + termination do most of the work
+    assert st["replay_rays"] < 0.2 * st["rays_hit"]
+    # the same frame in reference order with skipping fetches more taps but far fewer than all
+    ctx.set_mode(2)
+    img2, st2 = ctx.render(256, 256, stats=True)
+    assert np.array_equal(img2, img)
+    assert st["samples_evaluated"] < st2["samples_evaluated"] < st2["samples_nominal"]
+
+
+def test_fast_mode_falls_back_when_alpha_leaves_unit_interval(ctx, oracle):
+    # intensities are UI-clamped to [0,1] in the reference, but the table is plain floats: with
+    # alpha > 1 the interval argument of the fast march does not hold and every ray is re-marched
+    graphs = [list(g) for g in cf.TF_GRAPHS]
+    graphs[3] = [(0.0, 0.0), (120.0, 0.0), (300.0, 0.4), (483.0, 1.7)]
+    got, want = render_pair(ctx, oracle, oracle.phantom(32, np.uint8), graphs, cf.CAMERAS["h30_v20"], 64, 64, 100, mode=1, stats=True)
+    img, st = got
+    check_frame(img, want, "alpha > 1")
+    assert st["replay_rays"] == st["rays_hit"]
+
+
+def test_nan_in_table(ctx, oracle):
+    graphs = cf.lut_cases()["duplicate_x_nan"][0]
+    for mode in (0, 1, 2):
+        got, want = render_pair(ctx, oracle, oracle.phantom(32, np.uint8), graphs, cf.CAMERAS["front"], 48, 48, 60, mode=mode)
+        check_frame(got, want, "NaN table mode %d" % mode)
+
+
+def test_opaque_border_colour_fast(ctx, oracle):
+    # hardware that honours "opaque black" gives the border alpha 1: air becomes half opaque
+    got, want = render_pair(ctx, oracle, oracle.phantom(48, np.uint16), cf.TF_GRAPHS, cf.CAMERAS["h30_v20"], 80, 80, 120,
+                            border=(0, 0, 0, 1), mode=1)
+    check_frame(got, want, "opaque border fast")
+
+
+def test_translucent_table_fast(ctx, oracle):
+    # low alphas everywhere: rays rarely terminate early, long accumulation chains
+    xs = (0.0, 60.0, 300.0, 483.0)
+    graphs = [list(zip(xs, c)) for c in ((0.2, .9, 1, 1), (0.1, .3, .8, 1), (0.3, .1, .5, 1), (0.0, 0.004, 0.01, 0.02))]
+    got, want = render_pair(ctx, oracle, oracle.phantom(64, np.uint16), graphs, cf.CAMERAS["hm135_vm60"], 96, 96, 300, mode=1, stats=True)
+    img, st = got
+    check_frame(img, want, "translucent fast")
+    print(st)
+
+
+def test_count_hit_rays(ctx, oracle):
+    ctx.upload_volume(np.ones((4, 4, 4), np.uint8))
+    for cam in cf.CAMERAS.values():
+        ctx.set_camera(*cam)
+        vp, m = oracle.camera(cam[0], cam[1], 200, 120)
+        assert ctx.count_hit_rays(200, 120) == oracle.count_hits(vp[4:8], m, 200, 120)

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvr_hip.so")
 
 DTYPE_U8, DTYPE_U16 = 1, 2
-MODE_REFERENCE_ORDER, MODE_FAST = 0, 1
+MODE_REFERENCE_ORDER, MODE_FAST, MODE_REFERENCE_SKIP = 0, 1, 2
 
 # every symbol include/vr_abi.h declares
 ABI_SYMBOLS = (
@@ -23,7 +23,8 @@ ABI_SYMBOLS = (
     "vr_read_volume_normalized", "vr_set_transfer_function", "vr_get_lut",
     "vr_control_point_intensity", "vr_set_camera", "vr_set_camera_raw", "vr_get_camera",
     "vr_camera_uniforms",
-    "vr_set_sampling", "vr_set_mode", "vr_render", "vr_render_rect", "vr_phantom_generate_device",
+    "vr_set_sampling", "vr_set_mode", "vr_render", "vr_render_rect", "vr_count_hit_rays",
+    "vr_phantom_generate_device",
 )
 
 
@@ -89,6 +90,7 @@ def lib():
     L.vr_set_mode.argtypes = [vp, C.c_int]
     L.vr_render.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.POINTER(Stats)]
     L.vr_render_rect.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.POINTER(Stats)]
+    L.vr_count_hit_rays.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
     L.vr_phantom_generate_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_uint32]
     for name in ABI_SYMBOLS:
         fn = getattr(L, name)
@@ -233,6 +235,12 @@ class VolumeRenderer:
         self._check(lib().vr_render_rect(self._h, width, height, x0, y0, x1, y1, out.ctypes.data, 0,
                                          C.byref(st) if stats else None))
         return (out, st.as_dict()) if stats else out
+
+    def count_hit_rays(self, width, height, rect=None):
+        x0, y0, x1, y1 = (0, 0, width, height) if rect is None else rect
+        n = C.c_uint64()
+        self._check(lib().vr_count_hit_rays(self._h, width, height, x0, y0, x1, y1, C.byref(n)))
+        return n.value
 
     def render_device(self, width, height, ptr, stats=False, rect=None):
         """Renders into device memory at `ptr`, asynchronously on the context's stream."""

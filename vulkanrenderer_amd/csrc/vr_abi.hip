@@ -15,7 +15,7 @@
 #include <vector>
 
 #include "vr_camera.hpp"
-#include "vr_kernels.hpp"
+#include "vr_march.hpp"
 
 struct vr_ctx {
     int device = 0;
@@ -27,7 +27,10 @@ struct vr_ctx {
     void *bricks = nullptr;
     uint32_t *cells = nullptr;
     uint32_t *touched = nullptr;  // one bit per brick, stats only
+    uint32_t *empty_fine = nullptr, *empty_coarse = nullptr;  // occupancy for the current table
     size_t brick_count = 0;
+    int ncx = 0, ncy = 0, ncz = 0;
+    bool occupancy_dirty = true;
     int dtype = 0, nx = 0, ny = 0, nz = 0, nbx = 0, nby = 0, nbz = 0;
     float max_value = 0.0f, inv_hi = 0.0f, inv_lo = 0.0f;
 
@@ -47,8 +50,11 @@ struct vr_ctx {
     int mode = VR_MODE_REFERENCE_ORDER;
 
     vr::Counters *counters = nullptr;  // device
+    vr::LutInfo *lut_info = nullptr;   // device
     uint32_t *frame = nullptr;         // device staging for host-pointer renders
     size_t frame_cap = 0;
+    uint32_t *queue = nullptr;         // pixels the fast march hands to the reference-order march
+    size_t queue_cap = 0;
 };
 
 namespace {
@@ -77,9 +83,14 @@ void release_volume(vr_ctx *ctx)
     if (ctx->bricks) (void)hipFree(ctx->bricks);
     if (ctx->cells) (void)hipFree(ctx->cells);
     if (ctx->touched) (void)hipFree(ctx->touched);
+    if (ctx->empty_fine) (void)hipFree(ctx->empty_fine);
+    if (ctx->empty_coarse) (void)hipFree(ctx->empty_coarse);
     ctx->bricks = nullptr;
     ctx->cells = nullptr;
     ctx->touched = nullptr;
+    ctx->empty_fine = nullptr;
+    ctx->empty_coarse = nullptr;
+    ctx->occupancy_dirty = true;
     ctx->brick_count = 0;
     ctx->dtype = 0;
 }
@@ -94,6 +105,9 @@ vr::VolumeView view_of(const vr_ctx *ctx)
     v.fx = (float)ctx->nx; v.fy = (float)ctx->ny; v.fz = (float)ctx->nz;
     v.inv_hi = ctx->inv_hi; v.inv_lo = ctx->inv_lo;
     v.max_value = ctx->max_value;
+    v.empty_fine = ctx->empty_fine;
+    v.empty_coarse = ctx->empty_coarse;
+    v.ncx = ctx->ncx; v.ncy = ctx->ncy; v.ncz = ctx->ncz;
     return v;
 }
 
@@ -139,6 +153,12 @@ int ingest_device(vr_ctx *ctx, T *d_raw, int nx, int ny, int nz, float max_value
     VR_HIP(ctx, hipMalloc(&ctx->bricks, ctx->brick_count * vr::kBrickElems * sizeof(T)));
     VR_HIP(ctx, hipMalloc(&ctx->cells, ctx->brick_count * sizeof(uint32_t)));
     VR_HIP(ctx, hipMalloc(&ctx->touched, ((ctx->brick_count + 31) / 32) * sizeof(uint32_t)));
+    ctx->ncx = (ctx->nbx + 3) / 4;
+    ctx->ncy = (ctx->nby + 3) / 4;
+    ctx->ncz = (ctx->nbz + 3) / 4;
+    VR_HIP(ctx, hipMalloc(&ctx->empty_fine, ((ctx->brick_count + 31) / 32) * sizeof(uint32_t)));
+    VR_HIP(ctx, hipMalloc(&ctx->empty_coarse, (((size_t)ctx->ncx * ctx->ncy * ctx->ncz + 31) / 32) * sizeof(uint32_t)));
+    ctx->occupancy_dirty = true;
     hipLaunchKernelGGL((vr::k_build_bricks<T>), dim3((unsigned)ctx->brick_count), dim3(256), 0, ctx->stream,
                        (const T *)d_raw, (T *)ctx->bricks, ctx->cells, nx, ny, nz, ctx->nbx, ctx->nby);
     VR_HIP(ctx, hipGetLastError());
@@ -151,6 +171,56 @@ int check_dims(vr_ctx *ctx, int dtype, int nx, int ny, int nz)
     if (dtype != VR_DTYPE_U8 && dtype != VR_DTYPE_U16) return fail(ctx, VR_ERR_ARG, "dtype must be VR_DTYPE_U8 or VR_DTYPE_U16");
     if (nx < 1 || ny < 1 || nz < 1 || nx > 8192 || ny > 8192 || nz > 8192) return fail(ctx, VR_ERR_ARG, "volume dimensions out of range");
     return VR_OK;
+}
+
+// Brings the occupancy bits up to date with the current table, border colour and volume.
+int refresh_occupancy(vr_ctx *ctx)
+{
+    if (!ctx->occupancy_dirty) return VR_OK;
+    const float4 border = make_float4(ctx->border[0], ctx->border[1], ctx->border[2], ctx->border[3]);
+    hipLaunchKernelGGL(vr::k_lut_derive, dim3(1), dim3(256), 0, ctx->stream, reinterpret_cast<const float4 *>(ctx->lut), border,
+                       ctx->lut_info);
+    const unsigned bricks = (unsigned)ctx->brick_count;
+    hipLaunchKernelGGL(vr::k_classify_bricks, dim3((bricks + 255) / 256), dim3(256), 0, ctx->stream, ctx->cells, bricks, ctx->inv_hi,
+                       ctx->inv_lo, ctx->lut_info, ctx->empty_fine);
+    const unsigned cells = (unsigned)(ctx->ncx * ctx->ncy * ctx->ncz);
+    hipLaunchKernelGGL(vr::k_classify_coarse, dim3((cells + 255) / 256), dim3(256), 0, ctx->stream, ctx->empty_fine, ctx->nbx, ctx->nby,
+                       ctx->nbz, ctx->ncx, ctx->ncy, ctx->ncz, ctx->empty_coarse);
+    VR_HIP(ctx, hipGetLastError());
+    ctx->occupancy_dirty = false;
+    return VR_OK;
+}
+
+template <typename T>
+void launch_frame(vr_ctx *ctx, const vr::FrameParams &fp, uint32_t *d_out, bool stats)
+{
+    const int tiles_x = (fp.x1 - fp.x0 + 15) / 16, tiles_y = (fp.y1 - fp.y0 + 15) / 16;
+    const dim3 grid((unsigned)(tiles_x * tiles_y)), block(256);
+    const vr::VolumeView vol = view_of(ctx);
+    const float4 border = make_float4(ctx->border[0], ctx->border[1], ctx->border[2], ctx->border[3]);
+    const float4 *lut = reinterpret_cast<const float4 *>(ctx->lut);
+    hipStream_t s = ctx->stream;
+    if (ctx->mode == VR_MODE_REFERENCE_ORDER) {
+        if (stats)
+            hipLaunchKernelGGL((vr::k_march_exact<T, false, true, false>), grid, block, 0, s, vol, fp, lut, border, d_out, ctx->counters, ctx->touched, nullptr);
+        else
+            hipLaunchKernelGGL((vr::k_march_exact<T, false, false, false>), grid, block, 0, s, vol, fp, lut, border, d_out, ctx->counters, ctx->touched, nullptr);
+    } else if (ctx->mode == VR_MODE_REFERENCE_SKIP) {
+        if (stats)
+            hipLaunchKernelGGL((vr::k_march_exact<T, true, true, false>), grid, block, 0, s, vol, fp, lut, border, d_out, ctx->counters, ctx->touched, nullptr);
+        else
+            hipLaunchKernelGGL((vr::k_march_exact<T, true, false, false>), grid, block, 0, s, vol, fp, lut, border, d_out, ctx->counters, ctx->touched, nullptr);
+    } else {
+        // front-to-back march, then the rays it could not decide in reference order
+        const dim3 replay_grid(1024);
+        if (stats) {
+            hipLaunchKernelGGL((vr::k_march_fast<T, true>), grid, block, 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue);
+            hipLaunchKernelGGL((vr::k_march_exact<T, true, true, true>), replay_grid, block, 0, s, vol, fp, lut, border, d_out, ctx->counters, ctx->touched, ctx->queue);
+        } else {
+            hipLaunchKernelGGL((vr::k_march_fast<T, false>), grid, block, 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue);
+            hipLaunchKernelGGL((vr::k_march_exact<T, true, false, true>), replay_grid, block, 0, s, vol, fp, lut, border, d_out, ctx->counters, ctx->touched, ctx->queue);
+        }
+    }
 }
 
 }  // namespace
@@ -169,6 +239,7 @@ int vr_create(int device, vr_ctx **out)
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
         hipMalloc(&ctx->lut, 1024 * sizeof(float)) != hipSuccess ||
         hipMalloc(&ctx->counters, sizeof(vr::Counters)) != hipSuccess ||
+        hipMalloc(&ctx->lut_info, sizeof(vr::LutInfo)) != hipSuccess ||
         hipMemset(ctx->lut, 0, 1024 * sizeof(float)) != hipSuccess ||  // main.cpp:110: zero-initialised table
         hipMemset(ctx->counters, 0, sizeof(vr::Counters)) != hipSuccess ||
         hipMemcpyToSymbol(HIP_SYMBOL(vr::d_phantom), vr::PHANTOM, sizeof(vr::PHANTOM)) != hipSuccess) {
@@ -189,6 +260,8 @@ int vr_destroy(vr_ctx *ctx)
     if (ctx->d_pts) (void)hipFree(ctx->d_pts);
     if (ctx->counters) (void)hipFree(ctx->counters);
     if (ctx->frame) (void)hipFree(ctx->frame);
+    if (ctx->queue) (void)hipFree(ctx->queue);
+    if (ctx->lut_info) (void)hipFree(ctx->lut_info);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -337,6 +410,7 @@ int vr_set_transfer_function(vr_ctx *ctx, const vr_ctrl_pt *const points[4], con
         VR_HIP(ctx, hipMalloc(&ctx->d_pts, cap * sizeof(vr::CtrlPt)));
         ctx->d_pts_cap = cap;
     }
+    ctx->occupancy_dirty = true;
     if (reset_state) VR_HIP(ctx, hipMemsetAsync(ctx->lut, 0, 1024 * sizeof(float), ctx->stream));
     if (!packed.empty()) {
         // synchronous on purpose: `packed` lives on this stack frame
@@ -410,14 +484,17 @@ int vr_set_sampling(vr_ctx *ctx, int samples_per_ray, const float tf_border_rgba
     if (!ctx) return VR_ERR_ARG;
     if (samples_per_ray < 0 || samples_per_ray > (1 << 20)) return fail(ctx, VR_ERR_ARG, "samples_per_ray out of range");
     ctx->samples = samples_per_ray;
-    if (tf_border_rgba) std::memcpy(ctx->border, tf_border_rgba, sizeof ctx->border);
+    if (tf_border_rgba && std::memcmp(ctx->border, tf_border_rgba, sizeof ctx->border) != 0) {
+        std::memcpy(ctx->border, tf_border_rgba, sizeof ctx->border);
+        ctx->occupancy_dirty = true;
+    }
     return VR_OK;
 }
 
 int vr_set_mode(vr_ctx *ctx, int mode)
 {
     if (!ctx) return VR_ERR_ARG;
-    if (mode != VR_MODE_REFERENCE_ORDER && mode != VR_MODE_FAST) return fail(ctx, VR_ERR_ARG, "unknown mode");
+    if (mode != VR_MODE_REFERENCE_ORDER && mode != VR_MODE_FAST && mode != VR_MODE_REFERENCE_SKIP) return fail(ctx, VR_ERR_ARG, "unknown mode");
     ctx->mode = mode;
     return VR_OK;
 }
@@ -453,28 +530,26 @@ int vr_render_rect(vr_ctx *ctx, int width, int height, int x0, int y0, int x1, i
         d_out = ctx->frame;
     }
     const bool want_stats = stats != nullptr;
-    if (want_stats) {
-        VR_HIP(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(vr::Counters), ctx->stream));
-        VR_HIP(ctx, hipMemsetAsync(ctx->touched, 0, ((ctx->brick_count + 31) / 32) * sizeof(uint32_t), ctx->stream));
+    const bool fast = ctx->mode == VR_MODE_FAST;
+    if (fast && pixels > ctx->queue_cap) {
+        if (ctx->queue) (void)hipFree(ctx->queue);
+        ctx->queue = nullptr;
+        ctx->queue_cap = 0;
+        VR_HIP(ctx, hipMalloc(&ctx->queue, pixels * sizeof(uint32_t)));
+        ctx->queue_cap = pixels;
     }
-    const int tiles_x = (x1 - x0 + 15) / 16, tiles_y = (y1 - y0 + 15) / 16;
-    const dim3 grid((unsigned)(tiles_x * tiles_y)), block(256);
-    const vr::VolumeView vol = view_of(ctx);
-    const float4 border = make_float4(ctx->border[0], ctx->border[1], ctx->border[2], ctx->border[3]);
-    const float4 *lut = reinterpret_cast<const float4 *>(ctx->lut);
+    if (ctx->mode != VR_MODE_REFERENCE_ORDER)
+        if (int rc = refresh_occupancy(ctx)) return rc;
+    // the counters also carry the fast march's queue fill, so they are cleared every frame
+    VR_HIP(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(vr::Counters), ctx->stream));
+    if (want_stats)
+        VR_HIP(ctx, hipMemsetAsync(ctx->touched, 0, ((ctx->brick_count + 31) / 32) * sizeof(uint32_t), ctx->stream));
 
     VR_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    if (ctx->dtype == VR_DTYPE_U8) {
-        if (want_stats)
-            hipLaunchKernelGGL((vr::k_march_reference<uint8_t, true>), grid, block, 0, ctx->stream, vol, fp, lut, border, d_out, ctx->counters, ctx->touched);
-        else
-            hipLaunchKernelGGL((vr::k_march_reference<uint8_t, false>), grid, block, 0, ctx->stream, vol, fp, lut, border, d_out, ctx->counters, ctx->touched);
-    } else {
-        if (want_stats)
-            hipLaunchKernelGGL((vr::k_march_reference<uint16_t, true>), grid, block, 0, ctx->stream, vol, fp, lut, border, d_out, ctx->counters, ctx->touched);
-        else
-            hipLaunchKernelGGL((vr::k_march_reference<uint16_t, false>), grid, block, 0, ctx->stream, vol, fp, lut, border, d_out, ctx->counters, ctx->touched);
-    }
+    if (ctx->dtype == VR_DTYPE_U8)
+        launch_frame<uint8_t>(ctx, fp, d_out, want_stats);
+    else
+        launch_frame<uint16_t>(ctx, fp, d_out, want_stats);
     VR_HIP(ctx, hipGetLastError());
     VR_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
 
@@ -499,7 +574,9 @@ int vr_render_rect(vr_ctx *ctx, int width, int height, int x0, int y0, int x1, i
         stats->bricks_touched = touched;
         stats->replay_rays = c.replay_rays;
         const uint64_t brick_bytes = (uint64_t)vr::kBrick * vr::kBrick * vr::kBrick * (uint64_t)ctx->dtype;
-        stats->algorithmic_bytes = brick_bytes * touched + 4ull * touched + (uint64_t)vr::kLutLds * 16ull + 4ull * pixels;
+        // bricks fetched + (fast/skip modes) one occupancy bit per brick and per supercell + LUT + frame
+        const uint64_t occupancy = ctx->mode == VR_MODE_REFERENCE_ORDER ? 0 : (ctx->brick_count + 7) / 8 + ((uint64_t)ctx->ncx * ctx->ncy * ctx->ncz + 7) / 8;
+        stats->algorithmic_bytes = brick_bytes * touched + occupancy + (uint64_t)vr::kLutLds * 16ull + 4ull * pixels;
         float ms = 0.0f;
         VR_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
         stats->kernel_ms = ms;
@@ -510,6 +587,30 @@ int vr_render_rect(vr_ctx *ctx, int width, int height, int x0, int y0, int x1, i
 int vr_render(vr_ctx *ctx, int width, int height, uint8_t *out, int out_is_device, vr_stats *stats)
 {
     return vr_render_rect(ctx, width, height, 0, 0, width, height, out, out_is_device, stats);
+}
+
+int vr_count_hit_rays(vr_ctx *ctx, int width, int height, int x0, int y0, int x1, int y1, uint64_t *hits)
+{
+    if (!ctx || !hits) return fail(ctx, VR_ERR_ARG, "null argument");
+    if (width < 2 || height < 2 || x0 < 0 || y0 < 0 || x1 > width || y1 > height || x0 >= x1 || y0 >= y1)
+        return fail(ctx, VR_ERR_ARG, "bad image size or pixel rectangle");
+    if (int rc = bind(ctx)) return rc;
+    vr::FrameParams fp;
+    float pyramid[20];
+    if (int rc = vr_get_camera(ctx, width, height, pyramid, fp.m)) return rc;
+    std::memcpy(fp.loc, pyramid + 4, sizeof fp.loc);
+    fp.width = width; fp.height = height;
+    fp.x0 = x0; fp.y0 = y0; fp.x1 = x1; fp.y1 = y1;
+    fp.samples = ctx->samples;
+    fp.pad_ = 0;
+    VR_HIP(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(vr::Counters), ctx->stream));
+    const int tiles_x = (x1 - x0 + 15) / 16, tiles_y = (y1 - y0 + 15) / 16;
+    hipLaunchKernelGGL(vr::k_count_hits, dim3((unsigned)(tiles_x * tiles_y)), dim3(256), 0, ctx->stream, fp, &ctx->counters->rays_hit);
+    unsigned long long h = 0;
+    VR_HIP(ctx, hipMemcpyAsync(&h, &ctx->counters->rays_hit, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    VR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *hits = h;
+    return VR_OK;
 }
 
 int vr_phantom_generate_device(vr_ctx *ctx, void *d_out, int dtype, int n, uint32_t seed)

@@ -34,6 +34,11 @@ struct VolumeView {
     float fx, fy, fz;       // (float) nx, ny, nz
     float inv_hi, inv_lo;   // 1/max split in two floats: v/max == fma(v, inv_hi, v*inv_lo) exactly
     float max_value;
+    // Occupancy for the current transfer function: one bit per brick / per 4^3-brick supercell,
+    // set when no tap whose low corner lies inside can receive a non-zero alpha.
+    const uint32_t *empty_fine;
+    const uint32_t *empty_coarse;
+    int ncx, ncy, ncz;      // supercells
 };
 
 struct FrameParams {
@@ -236,56 +241,6 @@ __device__ __forceinline__ void lane_pixel(const FrameParams &fp, int &px, int &
     const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
     px = fp.x0 + bx * 16 + (wave & 1) * 8 + (lane & 7);
     py = fp.y0 + by * 16 + (wave >> 1) * 8 + (lane >> 3);
-}
-
-// ---- reference-order march -------------------------------------------------------------------
-// Back to front over all samples + 2 taps exactly as the shader loops (VolumeRendering.comp:
-// 183-202).  With SKIP, a tap whose brick has a (min,max) range over which the transfer
-// function's alpha is exactly zero is not fetched: such a tap leaves the colour unchanged bit for
-// bit (0*c + 1*C), the back-most tap (t == 0) excepted, which is never skipped because the shader
-// assigns there instead of blending.
-template <typename T, bool STATS>
-__global__ __launch_bounds__(256) void k_march_reference(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
-                                                        float4 border, uint32_t *__restrict__ out,
-                                                        Counters *ctr, uint32_t *touched)
-{
-    __shared__ float4 s_lut[kLutLds];
-    stage_lut(s_lut, lut, border);
-    int px, py;
-    lane_pixel(fp, px, py);
-    if (px >= fp.x1 || py >= fp.y1) return;
-
-    const Ray r = make_ray(fp, px, py);
-    float cr = 0.0f, cg = 0.0f, cb = 0.0f;
-    unsigned long long evaluated = 0;
-    if (r.hit) {
-        const int last = fp.samples + 1;
-        const float step = (r.tmax - r.tmin) / (float)(uint32_t)last;
-        for (int t = 0; t <= last; t++) {
-            const Tap p = tap_position(r, vol, step, t);
-            const Cell c = tap_cell(p, vol);
-            const uint32_t brick = brick_of(c, vol);
-            const float inten = sample_volume<T>(c, brick, vol);
-            const float4 tf = sample_tf(s_lut, inten);
-            if (t == 0) {
-                cr = tf.x; cg = tf.y; cb = tf.z;
-            } else {
-                const float a = tf.w, ia = 1.0f - tf.w;
-                cr = a * tf.x + ia * cr;
-                cg = a * tf.y + ia * cg;
-                cb = a * tf.z + ia * cb;
-            }
-            if (STATS) {
-                evaluated++;
-                atomicOr(&touched[brick >> 5], 1u << (brick & 31));
-            }
-        }
-    }
-    out[(size_t)(py - fp.y0) * (fp.x1 - fp.x0) + (px - fp.x0)] = pack_rgba8(cr, cg, cb);
-    if (STATS) {
-        atomicAdd(&ctr->rays_hit, r.hit ? 1ull : 0ull);
-        atomicAdd(&ctr->samples_evaluated, evaluated);
-    }
 }
 
 // ---- transfer function table ---------------------------------------------------------------
