@@ -126,6 +126,23 @@ int vr_render(vr_ctx *ctx, int width, int height, uint8_t *out, int out_is_devic
 int vr_render_rect(vr_ctx *ctx, int width, int height, int x0, int y0, int x1, int y1,
                    uint8_t *out, int out_is_device, vr_stats *stats);
 
+/* Sort-first split for multi-GPU rendering (no counterpart in the reference, which drives one
+ * GPU): the frame's rows are cut into bands of 16 rows, dealt round-robin to `parts` renderers;
+ * this call renders the bands b with b % parts == part in one launch and writes them densely,
+ * band after band: out holds vr_band_rows(height, part, parts) * width * 4 bytes.  Pixels are
+ * independent (VolumeRendering.comp:159 uses only its own invocation id), so the union of the
+ * parts is the frame vr_render produces. */
+int vr_render_bands(vr_ctx *ctx, int width, int height, int part, int parts,
+                    uint8_t *out, int out_is_device, vr_stats *stats);
+/* Rows a part owns (>= 0), or VR_ERR_ARG. */
+int vr_band_rows(int height, int part, int parts);
+
+/* Device time (ms, HIP events on the context's stream) of the main march kernel of the most
+ * recent frames, oldest first: at most `capacity` and at most the last 1024 frames.  Waits for
+ * the stream.  Measurement aid (the reference only shows whole-loop FPS in the window title,
+ * Source/VulkanApplication.cpp:617-620). */
+int vr_march_kernel_times(vr_ctx *ctx, float *ms, int capacity, int *count);
+
 /* Number of rays of the rectangle that hit the volume box; the reference marches
  * samples_per_ray + 2 taps on each of them (VolumeRendering.comp:180-184). */
 int vr_count_hit_rays(vr_ctx *ctx, int width, int height, int x0, int y0, int x1, int y1, uint64_t *hits);

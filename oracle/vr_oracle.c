@@ -529,6 +529,16 @@ void vro_render(const float *volume, uint32_t nx, uint32_t ny, uint32_t nz,
                  row0, row1, out, NULL, threads);
 }
 
+uint64_t vro_count_hits_rows(const float location[4], const float to_world[16],
+                             uint32_t width, uint32_t row0, uint32_t row1)
+{
+    uint64_t hits = 0;
+    for (uint32_t py = row0; py < row1; py++)
+        for (uint32_t px = 0; px < width; px++)
+            hits += (uint64_t)make_ray(location, to_world, (int)px, (int)py).hit;
+    return hits;
+}
+
 uint64_t vro_count_hits(const float location[4], const float to_world[16],
                         uint32_t width, uint32_t height)
 {

@@ -80,6 +80,8 @@ void vro_render_f(const float *volume, uint32_t nx, uint32_t ny, uint32_t nz,
 /* Number of rays of the frame that hit the box (for the nominal sample count). */
 uint64_t vro_count_hits(const float location[4], const float to_world[16],
                         uint32_t width, uint32_t height);
+uint64_t vro_count_hits_rows(const float location[4], const float to_world[16],
+                             uint32_t width, uint32_t row0, uint32_t row1);
 
 /* Synthetic CT phantom (not part of the reference; the measurement input of this build):
  * 3-D Shepp-Logan, n^3 voxels, dtype_bytes 1 or 2, little-endian raw, x fastest. */

@@ -58,6 +58,8 @@ def lib():
         L.vro_render_f.restype = None
         L.vro_count_hits.argtypes = [fp, fp, C.c_uint32, C.c_uint32]
         L.vro_count_hits.restype = C.c_uint64
+        L.vro_count_hits_rows.argtypes = [fp, fp, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.vro_count_hits_rows.restype = C.c_uint64
         L.vro_phantom.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32]
         L.vro_phantom.restype = None
         L.vro_threads.restype = C.c_int
@@ -151,10 +153,11 @@ def render(volume, lut, location, to_world, width, height, samples=200,
     return (out, col) if want_colour else out
 
 
-def count_hits(location, to_world, width, height):
+def count_hits(location, to_world, width, height, rows=None):
     loc = np.ascontiguousarray(location, np.float32).ravel()
     m = np.ascontiguousarray(to_world, np.float32).ravel()
-    return int(lib().vro_count_hits(_fp(loc), _fp(m), width, height))
+    r0, r1 = (0, height) if rows is None else rows
+    return int(lib().vro_count_hits_rows(_fp(loc), _fp(m), width, r0, r1))
 
 
 def phantom(n, dtype=np.uint16, seed=0x5EED1234):

@@ -23,7 +23,8 @@ ABI_SYMBOLS = (
     "vr_read_volume_normalized", "vr_set_transfer_function", "vr_get_lut",
     "vr_control_point_intensity", "vr_set_camera", "vr_set_camera_raw", "vr_get_camera",
     "vr_camera_uniforms",
-    "vr_set_sampling", "vr_set_mode", "vr_render", "vr_render_rect", "vr_count_hit_rays",
+    "vr_set_sampling", "vr_set_mode", "vr_render", "vr_render_rect", "vr_render_bands",
+    "vr_band_rows", "vr_march_kernel_times", "vr_count_hit_rays",
     "vr_phantom_generate_device",
 )
 
@@ -90,6 +91,9 @@ def lib():
     L.vr_set_mode.argtypes = [vp, C.c_int]
     L.vr_render.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.POINTER(Stats)]
     L.vr_render_rect.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.POINTER(Stats)]
+    L.vr_render_bands.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.POINTER(Stats)]
+    L.vr_band_rows.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.vr_march_kernel_times.argtypes = [vp, fp, C.c_int, C.POINTER(C.c_int)]
     L.vr_count_hit_rays.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
     L.vr_phantom_generate_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_uint32]
     for name in ABI_SYMBOLS:
@@ -112,6 +116,22 @@ def camera_uniforms(horizontal_rad, vertical_rad, width, height):
     if rc != 0:
         raise VrError("vr_camera_uniforms failed with %d" % rc)
     return vp, m
+
+
+def band_rows(height, part, parts):
+    """Rows of a height-row frame that sort-first part `part` of `parts` renders."""
+    n = lib().vr_band_rows(height, part, parts)
+    if n < 0:
+        raise VrError("vr_band_rows: bad arguments")
+    return n
+
+
+def band_row_indices(height, part, parts):
+    """Frame row of every row of the part's dense band buffer (host arithmetic, mirrors the kernel)."""
+    rows = []
+    for band in range(part, (height + 15) // 16, parts):
+        rows.extend(range(band * 16, min(height, band * 16 + 16)))
+    return np.asarray(rows, np.int64)
 
 
 def control_point_intensity(y, child_height):
@@ -235,6 +255,28 @@ class VolumeRenderer:
         self._check(lib().vr_render_rect(self._h, width, height, x0, y0, x1, y1, out.ctypes.data, 0,
                                          C.byref(st) if stats else None))
         return (out, st.as_dict()) if stats else out
+
+    def render_bands(self, width, height, part, parts, ptr=None, stats=False):
+        """Sort-first share of a frame: the 16-row bands b with b % parts == part, densely packed.
+        With ptr (device memory) the call is asynchronous and returns only the stats."""
+        rows = band_rows(height, part, parts)
+        st = Stats() if stats else None
+        out = None
+        if ptr is None:
+            out = np.empty((rows, width, 4), np.uint8)
+        self._check(lib().vr_render_bands(self._h, width, height, part, parts,
+                                          out.ctypes.data if ptr is None else ptr, 0 if ptr is None else 1,
+                                          C.byref(st) if stats else None))
+        if ptr is None:
+            return (out, st.as_dict()) if stats else out
+        return st.as_dict() if stats else None
+
+    def march_kernel_times(self, frames):
+        """Device milliseconds of the march kernel of the last `frames` frames (<= 1024)."""
+        ms = np.zeros(max(1, frames), np.float32)
+        n = C.c_int()
+        self._check(lib().vr_march_kernel_times(self._h, _fp(ms), frames, C.byref(n)))
+        return ms[:n.value].copy()
 
     def count_hit_rays(self, width, height, rect=None):
         x0, y0, x1, y1 = (0, 0, width, height) if rect is None else rect

@@ -21,6 +21,10 @@ struct vr_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // ring of event pairs around the main march kernel of the most recent frames
+    static constexpr int kRing = 1024;
+    std::vector<hipEvent_t> ring_a, ring_b;
+    uint64_t frames = 0;
     std::string error;
 
     // volume
@@ -159,8 +163,9 @@ int ingest_device(vr_ctx *ctx, T *d_raw, int nx, int ny, int nz, float max_value
     VR_HIP(ctx, hipMalloc(&ctx->empty_fine, ((ctx->brick_count + 31) / 32) * sizeof(uint32_t)));
     VR_HIP(ctx, hipMalloc(&ctx->empty_coarse, (((size_t)ctx->ncx * ctx->ncy * ctx->ncz + 31) / 32) * sizeof(uint32_t)));
     ctx->occupancy_dirty = true;
-    hipLaunchKernelGGL((vr::k_build_bricks<T>), dim3((unsigned)ctx->brick_count), dim3(256), 0, ctx->stream,
-                       (const T *)d_raw, (T *)ctx->bricks, ctx->cells, nx, ny, nz, ctx->nbx, ctx->nby);
+    const unsigned brick_blocks = (unsigned)std::min<size_t>(ctx->brick_count, 1u << 20);
+    hipLaunchKernelGGL((vr::k_build_bricks<T>), dim3(brick_blocks), dim3(256), 0, ctx->stream, (const T *)d_raw,
+                       (T *)ctx->bricks, ctx->cells, nx, ny, nz, ctx->nbx, ctx->nby, (uint32_t)ctx->brick_count);
     VR_HIP(ctx, hipGetLastError());
     VR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return VR_OK;
@@ -191,33 +196,56 @@ int refresh_occupancy(vr_ctx *ctx)
     return VR_OK;
 }
 
+// Sort-first split of `rows` image rows into 16-row bands dealt round-robin to `parts` parts.
+int bands_of_part(int rows, int part, int parts)
+{
+    const int bands = (rows + 15) / 16;
+    return bands > part ? (bands - part + parts - 1) / parts : 0;
+}
+
+int rows_of_part(int rows, int part, int parts)
+{
+    const int bands = (rows + 15) / 16, mine = bands_of_part(rows, part, parts);
+    if (mine == 0) return 0;
+    const int last_band = part + (mine - 1) * parts;                       // global index of my last band
+    const int last_rows = last_band == bands - 1 ? rows - 16 * (bands - 1) : 16;  // the frame's last band may be short
+    return (mine - 1) * 16 + last_rows;
+}
+
 template <typename T>
 void launch_frame(vr_ctx *ctx, const vr::FrameParams &fp, uint32_t *d_out, bool stats)
 {
-    const int tiles_x = (fp.x1 - fp.x0 + 15) / 16, tiles_y = (fp.y1 - fp.y0 + 15) / 16;
-    const dim3 grid((unsigned)(tiles_x * tiles_y)), block(256);
+    const int tiles_x = (fp.x1 - fp.x0 + 15) / 16;
+    const dim3 grid((unsigned)(tiles_x * bands_of_part(fp.y1 - fp.y0, fp.part, fp.parts))), block(256);
     const vr::VolumeView vol = view_of(ctx);
     const float4 border = make_float4(ctx->border[0], ctx->border[1], ctx->border[2], ctx->border[3]);
     const float4 *lut = reinterpret_cast<const float4 *>(ctx->lut);
     hipStream_t s = ctx->stream;
+    const int slot = (int)(ctx->frames % (uint64_t)vr_ctx::kRing);
+    ctx->frames++;
+    (void)hipEventRecord(ctx->ring_a[slot], s);
     if (ctx->mode == VR_MODE_REFERENCE_ORDER) {
         if (stats)
             hipLaunchKernelGGL((vr::k_march_exact<T, false, true, false>), grid, block, 0, s, vol, fp, lut, border, d_out, ctx->counters, ctx->touched, nullptr);
         else
             hipLaunchKernelGGL((vr::k_march_exact<T, false, false, false>), grid, block, 0, s, vol, fp, lut, border, d_out, ctx->counters, ctx->touched, nullptr);
+        (void)hipEventRecord(ctx->ring_b[slot], s);
     } else if (ctx->mode == VR_MODE_REFERENCE_SKIP) {
         if (stats)
             hipLaunchKernelGGL((vr::k_march_exact<T, true, true, false>), grid, block, 0, s, vol, fp, lut, border, d_out, ctx->counters, ctx->touched, nullptr);
         else
             hipLaunchKernelGGL((vr::k_march_exact<T, true, false, false>), grid, block, 0, s, vol, fp, lut, border, d_out, ctx->counters, ctx->touched, nullptr);
+        (void)hipEventRecord(ctx->ring_b[slot], s);
     } else {
         // front-to-back march, then the rays it could not decide in reference order
         const dim3 replay_grid(1024);
         if (stats) {
             hipLaunchKernelGGL((vr::k_march_fast<T, true>), grid, block, 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue);
+            (void)hipEventRecord(ctx->ring_b[slot], s);
             hipLaunchKernelGGL((vr::k_march_exact<T, true, true, true>), replay_grid, block, 0, s, vol, fp, lut, border, d_out, ctx->counters, ctx->touched, ctx->queue);
         } else {
             hipLaunchKernelGGL((vr::k_march_fast<T, false>), grid, block, 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue);
+            (void)hipEventRecord(ctx->ring_b[slot], s);
             hipLaunchKernelGGL((vr::k_march_exact<T, true, false, true>), replay_grid, block, 0, s, vol, fp, lut, border, d_out, ctx->counters, ctx->touched, ctx->queue);
         }
     }
@@ -246,6 +274,13 @@ int vr_create(int device, vr_ctx **out)
         vr_destroy(ctx);
         return VR_ERR_HIP;
     }
+    ctx->ring_a.resize(vr_ctx::kRing, nullptr);
+    ctx->ring_b.resize(vr_ctx::kRing, nullptr);
+    for (int i = 0; i < vr_ctx::kRing; i++)
+        if (hipEventCreate(&ctx->ring_a[i]) != hipSuccess || hipEventCreate(&ctx->ring_b[i]) != hipSuccess) {
+            vr_destroy(ctx);
+            return VR_ERR_HIP;
+        }
     *out = ctx;
     return VR_OK;
 }
@@ -262,6 +297,10 @@ int vr_destroy(vr_ctx *ctx)
     if (ctx->frame) (void)hipFree(ctx->frame);
     if (ctx->queue) (void)hipFree(ctx->queue);
     if (ctx->lut_info) (void)hipFree(ctx->lut_info);
+    for (hipEvent_t e : ctx->ring_a)
+        if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->ring_b)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -499,10 +538,11 @@ int vr_set_mode(vr_ctx *ctx, int mode)
     return VR_OK;
 }
 
-int vr_render_rect(vr_ctx *ctx, int width, int height, int x0, int y0, int x1, int y1, uint8_t *out, int out_is_device,
-                   vr_stats *stats)
+static int render_impl(vr_ctx *ctx, int width, int height, int x0, int y0, int x1, int y1, int part, int parts, uint8_t *out,
+                       int out_is_device, vr_stats *stats)
 {
     if (!ctx || !out) return fail(ctx, VR_ERR_ARG, "null argument");
+    if (parts < 1 || part < 0 || part >= parts) return fail(ctx, VR_ERR_ARG, "bad sort-first part");
     if (!ctx->bricks) return fail(ctx, VR_ERR_STATE, "no volume uploaded");
     if (width < 2 || height < 2 || width > 65536 || height > 65536) return fail(ctx, VR_ERR_ARG, "image size out of range");
     if (x0 < 0 || y0 < 0 || x1 > width || y1 > height || x0 >= x1 || y0 >= y1) return fail(ctx, VR_ERR_ARG, "bad pixel rectangle");
@@ -515,9 +555,14 @@ int vr_render_rect(vr_ctx *ctx, int width, int height, int x0, int y0, int x1, i
     fp.width = width; fp.height = height;
     fp.x0 = x0; fp.y0 = y0; fp.x1 = x1; fp.y1 = y1;
     fp.samples = ctx->samples;
-    fp.pad_ = 0;
+    fp.part = part;
+    fp.parts = parts;
 
-    const size_t pixels = (size_t)(x1 - x0) * (y1 - y0);
+    const size_t pixels = (size_t)(x1 - x0) * (size_t)rows_of_part(y1 - y0, part, parts);
+    if (pixels == 0) {
+        if (stats) std::memset(stats, 0, sizeof *stats);
+        return VR_OK;
+    }
     uint32_t *d_out = reinterpret_cast<uint32_t *>(out);
     if (!out_is_device) {
         if (pixels > ctx->frame_cap) {
@@ -584,9 +629,41 @@ int vr_render_rect(vr_ctx *ctx, int width, int height, int x0, int y0, int x1, i
     return VR_OK;
 }
 
+int vr_render_rect(vr_ctx *ctx, int width, int height, int x0, int y0, int x1, int y1, uint8_t *out, int out_is_device,
+                   vr_stats *stats)
+{
+    return render_impl(ctx, width, height, x0, y0, x1, y1, 0, 1, out, out_is_device, stats);
+}
+
 int vr_render(vr_ctx *ctx, int width, int height, uint8_t *out, int out_is_device, vr_stats *stats)
 {
-    return vr_render_rect(ctx, width, height, 0, 0, width, height, out, out_is_device, stats);
+    return render_impl(ctx, width, height, 0, 0, width, height, 0, 1, out, out_is_device, stats);
+}
+
+int vr_render_bands(vr_ctx *ctx, int width, int height, int part, int parts, uint8_t *out, int out_is_device, vr_stats *stats)
+{
+    return render_impl(ctx, width, height, 0, 0, width, height, part, parts, out, out_is_device, stats);
+}
+
+int vr_march_kernel_times(vr_ctx *ctx, float *ms, int capacity, int *count)
+{
+    if (!ctx || !ms || !count || capacity < 0) return fail(ctx, VR_ERR_ARG, "null argument");
+    if (int rc = bind(ctx)) return rc;
+    VR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t have = std::min<uint64_t>(ctx->frames, (uint64_t)vr_ctx::kRing);
+    const int n = (int)std::min<uint64_t>(have, (uint64_t)capacity);
+    for (int i = 0; i < n; i++) {  // oldest of the n most recent frames first
+        const int slot = (int)((ctx->frames - (uint64_t)n + (uint64_t)i) % (uint64_t)vr_ctx::kRing);
+        VR_HIP(ctx, hipEventElapsedTime(&ms[i], ctx->ring_a[slot], ctx->ring_b[slot]));
+    }
+    *count = n;
+    return VR_OK;
+}
+
+int vr_band_rows(int height, int part, int parts)
+{
+    if (height < 1 || parts < 1 || part < 0 || part >= parts) return VR_ERR_ARG;
+    return rows_of_part(height, part, parts);
 }
 
 int vr_count_hit_rays(vr_ctx *ctx, int width, int height, int x0, int y0, int x1, int y1, uint64_t *hits)
@@ -602,7 +679,8 @@ int vr_count_hit_rays(vr_ctx *ctx, int width, int height, int x0, int y0, int x1
     fp.width = width; fp.height = height;
     fp.x0 = x0; fp.y0 = y0; fp.x1 = x1; fp.y1 = y1;
     fp.samples = ctx->samples;
-    fp.pad_ = 0;
+    fp.part = 0;
+    fp.parts = 1;
     VR_HIP(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(vr::Counters), ctx->stream));
     const int tiles_x = (x1 - x0 + 15) / 16, tiles_y = (y1 - y0 + 15) / 16;
     hipLaunchKernelGGL(vr::k_count_hits, dim3((unsigned)(tiles_x * tiles_y)), dim3(256), 0, ctx->stream, fp, &ctx->counters->rays_hit);

@@ -47,7 +47,9 @@ struct FrameParams {
     int width, height;
     int x0, y0, x1, y1;  // pixel rectangle to render
     int samples;         // shader constant `samples` (VolumeRendering.comp:173)
-    int pad_;
+    // Sort-first split: the rectangle's rows are cut into bands of 16 rows and this launch
+    // renders the bands b with b % parts == part, written densely one after the other.
+    int part, parts;
 };
 
 struct Counters {
@@ -234,13 +236,28 @@ __device__ __forceinline__ void stage_lut(float4 *s_lut, const float4 *lut, cons
 
 // Pixel owned by a lane: a block of 256 threads covers 16x16 pixels, wave w the 8x8 tile
 // (w & 1, w >> 1), lane l the pixel (l & 7, l >> 3) of it.
-__device__ __forceinline__ void lane_pixel(const FrameParams &fp, int &px, int &py)
+// Returns false for lanes outside the rectangle.  out_index is the pixel's position in the output
+// buffer: rectangle rows, or with a sort-first split the rows of this part's bands, contiguous.
+__device__ __forceinline__ bool lane_pixel(const FrameParams &fp, int &px, int &py, uint32_t &out_index)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tiles_x = (fp.x1 - fp.x0 + 15) >> 4;
-    const int bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+    const int rect_w = fp.x1 - fp.x0;
+    const int tiles_x = (rect_w + 15) >> 4;
+    const int bx = blockIdx.x % tiles_x, band = blockIdx.x / tiles_x;   // band local to this part
+    const int row_in_band = (wave >> 1) * 8 + (lane >> 3);
     px = fp.x0 + bx * 16 + (wave & 1) * 8 + (lane & 7);
-    py = fp.y0 + by * 16 + (wave >> 1) * 8 + (lane >> 3);
+    py = fp.y0 + (band * fp.parts + fp.part) * 16 + row_in_band;
+    out_index = (uint32_t)((band * 16 + row_in_band) * rect_w + (px - fp.x0));
+    return px < fp.x1 && py < fp.y1;
+}
+
+// Inverse of out_index -> pixel, for the replay queue.
+__device__ __forceinline__ void pixel_of_index(const FrameParams &fp, uint32_t out_index, int &px, int &py)
+{
+    const uint32_t rect_w = (uint32_t)(fp.x1 - fp.x0);
+    const uint32_t row = out_index / rect_w;
+    px = fp.x0 + (int)(out_index - row * rect_w);
+    py = fp.y0 + (int)(((row >> 4) * (uint32_t)fp.parts + (uint32_t)fp.part) * 16u + (row & 15u));
 }
 
 // ---- transfer function table ---------------------------------------------------------------
@@ -315,9 +332,11 @@ __global__ __launch_bounds__(256) void k_swap_max(T *__restrict__ raw, size_t co
 template <typename T>
 __global__ __launch_bounds__(256) void k_build_bricks(const T *__restrict__ raw, T *__restrict__ bricks,
                                                      uint32_t *__restrict__ cells, int nx, int ny, int nz,
-                                                     int nbx, int nby)
+                                                     int nbx, int nby, uint32_t brick_count)
 {
-    const uint32_t brick = blockIdx.x;
+    __shared__ uint32_t s_mn[4], s_mx[4];
+    // a launch holds at most 2^32 - 1 threads, fewer than a 2048^3 volume has bricks x 256
+    for (uint32_t brick = blockIdx.x; brick < brick_count; brick += gridDim.x) {
     const int bx = brick % nbx, by = (brick / nbx) % nby, bz = brick / (nbx * nby);
     T *dst = bricks + (size_t)brick * kBrickElems;
     uint32_t mn = 0xffffffffu, mx = 0;
@@ -333,7 +352,6 @@ __global__ __launch_bounds__(256) void k_build_bricks(const T *__restrict__ raw,
         }
         dst[e] = (T)v;
     }
-    __shared__ uint32_t s_mn[4], s_mx[4];
     for (int o = 32; o > 0; o >>= 1) {
         const uint32_t a = __shfl_xor(mn, o), b = __shfl_xor(mx, o);
         mn = a < mn ? a : mn;
@@ -350,6 +368,8 @@ __global__ __launch_bounds__(256) void k_build_bricks(const T *__restrict__ raw,
             mx = s_mx[w] > mx ? s_mx[w] : mx;
         }
         cells[brick] = mn | (mx << 16);
+    }
+    __syncthreads();  // s_mn / s_mx are reused by the next brick
     }
 }
 

@@ -217,19 +217,17 @@ __global__ __launch_bounds__(256) void k_march_exact(VolumeView vol, FrameParams
 {
     __shared__ float4 s_lut[kLutLds];
     stage_lut(s_lut, lut, border);
-    const int rect_w = fp.x1 - fp.x0;
     uint32_t entry = blockIdx.x * 256u + threadIdx.x;
     const uint32_t stride = gridDim.x * 256u;
     const uint32_t entries = QUEUE ? ctr->replay_count : 1u;
     for (; QUEUE ? entry < entries : true; entry += stride) {
         int px, py;
+        uint32_t out_index;
         if (QUEUE) {
-            const uint32_t id = queue[entry];
-            px = fp.x0 + (int)(id % (uint32_t)rect_w);
-            py = fp.y0 + (int)(id / (uint32_t)rect_w);
+            out_index = queue[entry];
+            pixel_of_index(fp, out_index, px, py);
         } else {
-            lane_pixel(fp, px, py);
-            if (px >= fp.x1 || py >= fp.y1) return;
+            if (!lane_pixel(fp, px, py, out_index)) return;
         }
         const Ray r = make_ray(fp, px, py);
         float cr = 0.0f, cg = 0.0f, cb = 0.0f;
@@ -271,7 +269,7 @@ __global__ __launch_bounds__(256) void k_march_exact(VolumeView vol, FrameParams
                 t++;
             }
         }
-        out[(size_t)(py - fp.y0) * rect_w + (px - fp.x0)] = pack_rgba8(cr, cg, cb);
+        out[out_index] = pack_rgba8(cr, cg, cb);
         if (STATS) {
             if (!QUEUE) atomicAdd(&ctr->rays_hit, r.hit ? 1ull : 0ull);
             if (QUEUE) atomicAdd(&ctr->replay_rays, 1ull);
@@ -308,10 +306,8 @@ __global__ __launch_bounds__(256) void k_march_fast(VolumeView vol, FrameParams 
     __shared__ float4 s_lut[kLutLds];
     stage_lut(s_lut, lut, border);
     int px, py;
-    lane_pixel(fp, px, py);
-    const bool in_rect = px < fp.x1 && py < fp.y1;
-    const int rect_w = fp.x1 - fp.x0;
-    const uint32_t pixel_id = in_rect ? (uint32_t)((py - fp.y0) * rect_w + (px - fp.x0)) : 0u;
+    uint32_t pixel_id;
+    const bool in_rect = lane_pixel(fp, px, py, pixel_id);
 
     const Ray r = make_ray(fp, in_rect ? px : fp.x0, in_rect ? py : fp.y0);
     const bool fast_ok = info->fast_ok != 0;
@@ -430,8 +426,8 @@ __global__ __launch_bounds__(256) void k_march_fast(VolumeView vol, FrameParams 
 __global__ __launch_bounds__(256) void k_count_hits(FrameParams fp, unsigned long long *hits)
 {
     int px, py;
-    lane_pixel(fp, px, py);
-    const bool hit = px < fp.x1 && py < fp.y1 && make_ray(fp, px, py).hit;
+    uint32_t out_index;
+    const bool hit = lane_pixel(fp, px, py, out_index) && make_ray(fp, px, py).hit;
     const unsigned long long mask = __ballot(hit);
     if ((threadIdx.x & 63) == 0 && mask) atomicAdd(hits, (unsigned long long)__popcll(mask));
 }
