@@ -58,6 +58,8 @@ typedef struct vr_stats {
     uint64_t algorithmic_bytes; /* 1024 B (u16; 512 B u8) * bricks_touched + 4 B * distinct cells
                                    + LUT + 4 B * rays */
     float kernel_ms;            /* device time of the frame's kernels (hipEvent) */
+    uint32_t pad_;
+    uint64_t long_rays;         /* rays the lane-per-ray march handed to the wave-per-ray march */
 } vr_stats;
 
 /* Context life cycle.  Stands in for initComputePipeline / postRenderLoop,

@@ -1,0 +1,39 @@
+"""Renders a few frames of the benchmark workload and nothing else: the program to put after
+`rocprofv3 ... --` when collecting counters for the march kernels."""
+import argparse
+import math
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+import vulkanrenderer_amd as vr  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--volume", type=int, default=2048)
+ap.add_argument("--width", type=int, default=3840)
+ap.add_argument("--height", type=int, default=2160)
+ap.add_argument("--frames", type=int, default=4)
+ap.add_argument("--mode", type=int, default=1)
+a = ap.parse_args()
+n = a.volume
+ctx = vr.VolumeRenderer(0)
+raw = torch.empty(n ** 3, dtype=torch.int16, device="cuda")
+torch.cuda.synchronize()
+ctx.phantom_generate_device(raw.data_ptr(), 2, n)
+ctx.upload_volume_device(raw.data_ptr(), 2, n, n, n)
+ctx.synchronize()
+del raw
+ctx.update_transfer_function(bench.TF_GRAPHS, reset_state=True)
+ctx.set_sampling(bench.samples_for(n))
+ctx.set_mode(a.mode)
+out = torch.empty(a.width * a.height * 4, dtype=torch.uint8, device="cuda")
+torch.cuda.synchronize()
+for i in range(a.frames):
+    ctx.set_camera(*bench.orbit_camera(i * 30))
+    ctx.render_device(a.width, a.height, out.data_ptr())
+ctx.synchronize()
+print("ms", ctx.march_kernel_times(a.frames))
+ctx.close()

@@ -1,0 +1,68 @@
+"""Diagnostic: per-wave start/end times of the fast march (needs `make -C vulkanrenderer_amd/csrc diag`
+and VR_LIB_NAME=libvr_hip_diag.so).  Prints how many waves are resident over time."""
+import ctypes as C
+import math
+import os
+import sys
+
+os.environ.setdefault("VR_LIB_NAME", "libvr_hip_diag.so")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+import vulkanrenderer_amd as vr  # noqa: E402
+
+n, w, h = 2048, 3840, 2160
+ctx = vr.VolumeRenderer(0)
+raw = torch.empty(n ** 3, dtype=torch.int16, device="cuda")
+torch.cuda.synchronize()
+ctx.phantom_generate_device(raw.data_ptr(), 2, n)
+ctx.upload_volume_device(raw.data_ptr(), 2, n, n, n)
+ctx.synchronize()
+del raw
+ctx.update_transfer_function(bench.TF_GRAPHS, reset_state=True)
+ctx.set_sampling(bench.samples_for(n))
+ctx.set_mode(1)
+out = torch.empty(w * h * 4, dtype=torch.uint8, device="cuda")
+waves = ((w + 7) // 8) * ((h + 15) // 16) * 2 + 8
+tl = torch.zeros(waves * 4, dtype=torch.int64, device="cuda")
+torch.cuda.synchronize()
+L = vr.lib()
+L.vr_diag_set_timeline.argtypes = [C.c_void_p, C.c_void_p]
+for i in range(3):
+    ctx.set_camera(*bench.orbit_camera(30))
+    ctx.render_device(w, h, out.data_ptr())
+ctx.synchronize()
+assert L.vr_diag_set_timeline(ctx._h, tl.data_ptr()) == 0
+ctx.set_camera(*bench.orbit_camera(30))
+ctx.render_device(w, h, out.data_ptr())
+ctx.synchronize()
+print("kernel ms", ctx.march_kernel_times(1))
+t = tl.cpu().numpy().reshape(-1, 4)
+t = t[t[:, 0] != 0]
+t0, t1 = t[:, 0].astype(np.float64), t[:, 1].astype(np.float64)
+base = t0.min()
+t0 = (t0 - base) / 100.0   # us
+t1 = (t1 - base) / 100.0
+dur = t1 - t0
+print("waves", len(t), "span us", t1.max(), "dur us: mean %.1f median %.1f p90 %.1f p99 %.1f max %.1f" % (
+    dur.mean(), np.median(dur), np.percentile(dur, 90), np.percentile(dur, 99), dur.max()))
+edges = np.linspace(0, t1.max(), 41)
+for a, b in zip(edges[:-1], edges[1:]):
+    mid = 0.5 * (a + b)
+    resident = int(np.count_nonzero((t0 <= mid) & (t1 > mid)))
+    started = int(np.count_nonzero((t0 >= a) & (t0 < b)))
+    print("t=%7.0f us resident %6d (%.2f per SIMD) started %6d" % (mid, resident, resident / 1024.0, started))
+hw = t[:, 2]
+xcc = hw >> 32
+print("waves per XCC", np.bincount(xcc.astype(np.int64), minlength=8))
+# total work by duration: sum of durations vs span*slots
+print("sum dur (wave-us)", dur.sum(), "-> avg resident waves", dur.sum() / t1.max())
+# the longest waves: where are they in the image
+order = np.argsort(-dur)[:10]
+tiles_x = (w + 7) // 8
+ids = np.nonzero(tl.cpu().numpy().reshape(-1, 4)[:, 0])[0]
+for k in order:
+    wid = ids[k]
+    print("wave", wid, "tile", wid % tiles_x, wid // tiles_x, "dur us %.1f start %.0f" % (dur[k], t0[k]))

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvr_hip.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("VR_LIB_NAME", "libvr_hip.so"))
 
 DTYPE_U8, DTYPE_U16 = 1, 2
 MODE_REFERENCE_ORDER, MODE_FAST, MODE_REFERENCE_SKIP = 0, 1, 2
@@ -37,7 +37,8 @@ class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("rays_hit", C.c_uint64), ("samples_nominal", C.c_uint64),
                 ("samples_evaluated", C.c_uint64), ("cells_read", C.c_uint64),
                 ("bricks_touched", C.c_uint64), ("replay_rays", C.c_uint64),
-                ("algorithmic_bytes", C.c_uint64), ("kernel_ms", C.c_float)]
+                ("algorithmic_bytes", C.c_uint64), ("kernel_ms", C.c_float), ("pad_", C.c_uint32),
+                ("long_rays", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 #include <filesystem>
@@ -31,9 +32,9 @@ struct vr_ctx {
     void *bricks = nullptr;
     uint32_t *cells = nullptr;
     uint32_t *touched = nullptr;  // one bit per brick, stats only
-    uint32_t *empty_fine = nullptr, *empty_coarse = nullptr;  // occupancy for the current table
+    uint32_t *empty[vr::kLevels] = {nullptr, nullptr, nullptr, nullptr};  // occupancy pyramid for the current table
+    int lx[vr::kLevels] = {0}, ly[vr::kLevels] = {0}, lz[vr::kLevels] = {0};
     size_t brick_count = 0;
-    int ncx = 0, ncy = 0, ncz = 0;
     bool occupancy_dirty = true;
     int dtype = 0, nx = 0, ny = 0, nz = 0, nbx = 0, nby = 0, nbz = 0;
     float max_value = 0.0f, inv_hi = 0.0f, inv_lo = 0.0f;
@@ -50,6 +51,7 @@ struct vr_ctx {
     float raw_loc[4] = {0, 0, 0, 1};
     float raw_m[16] = {0};
 
+    int waves_per_block = 1;
     int samples = 200;  // VolumeRendering.comp:173
     int mode = VR_MODE_REFERENCE_ORDER;
 
@@ -59,6 +61,7 @@ struct vr_ctx {
     size_t frame_cap = 0;
     uint32_t *queue = nullptr;         // pixels the fast march hands to the reference-order march
     size_t queue_cap = 0;
+    vr::LongRay *long_queue = nullptr; // rays the lane march hands to the wave march
 };
 
 namespace {
@@ -87,13 +90,13 @@ void release_volume(vr_ctx *ctx)
     if (ctx->bricks) (void)hipFree(ctx->bricks);
     if (ctx->cells) (void)hipFree(ctx->cells);
     if (ctx->touched) (void)hipFree(ctx->touched);
-    if (ctx->empty_fine) (void)hipFree(ctx->empty_fine);
-    if (ctx->empty_coarse) (void)hipFree(ctx->empty_coarse);
+    for (int l = 0; l < vr::kLevels; l++) {
+        if (ctx->empty[l]) (void)hipFree(ctx->empty[l]);
+        ctx->empty[l] = nullptr;
+    }
     ctx->bricks = nullptr;
     ctx->cells = nullptr;
     ctx->touched = nullptr;
-    ctx->empty_fine = nullptr;
-    ctx->empty_coarse = nullptr;
     ctx->occupancy_dirty = true;
     ctx->brick_count = 0;
     ctx->dtype = 0;
@@ -109,9 +112,10 @@ vr::VolumeView view_of(const vr_ctx *ctx)
     v.fx = (float)ctx->nx; v.fy = (float)ctx->ny; v.fz = (float)ctx->nz;
     v.inv_hi = ctx->inv_hi; v.inv_lo = ctx->inv_lo;
     v.max_value = ctx->max_value;
-    v.empty_fine = ctx->empty_fine;
-    v.empty_coarse = ctx->empty_coarse;
-    v.ncx = ctx->ncx; v.ncy = ctx->ncy; v.ncz = ctx->ncz;
+    for (int l = 0; l < vr::kLevels; l++) {
+        v.empty[l] = ctx->empty[l];
+        v.lx[l] = ctx->lx[l]; v.ly[l] = ctx->ly[l]; v.lz[l] = ctx->lz[l];
+    }
     return v;
 }
 
@@ -157,11 +161,13 @@ int ingest_device(vr_ctx *ctx, T *d_raw, int nx, int ny, int nz, float max_value
     VR_HIP(ctx, hipMalloc(&ctx->bricks, ctx->brick_count * vr::kBrickElems * sizeof(T)));
     VR_HIP(ctx, hipMalloc(&ctx->cells, ctx->brick_count * sizeof(uint32_t)));
     VR_HIP(ctx, hipMalloc(&ctx->touched, ((ctx->brick_count + 31) / 32) * sizeof(uint32_t)));
-    ctx->ncx = (ctx->nbx + 3) / 4;
-    ctx->ncy = (ctx->nby + 3) / 4;
-    ctx->ncz = (ctx->nbz + 3) / 4;
-    VR_HIP(ctx, hipMalloc(&ctx->empty_fine, ((ctx->brick_count + 31) / 32) * sizeof(uint32_t)));
-    VR_HIP(ctx, hipMalloc(&ctx->empty_coarse, (((size_t)ctx->ncx * ctx->ncy * ctx->ncz + 31) / 32) * sizeof(uint32_t)));
+    for (int l = 0; l < vr::kLevels; l++) {
+        ctx->lx[l] = l == 0 ? ctx->nbx : (ctx->lx[l - 1] + 3) / 4;
+        ctx->ly[l] = l == 0 ? ctx->nby : (ctx->ly[l - 1] + 3) / 4;
+        ctx->lz[l] = l == 0 ? ctx->nbz : (ctx->lz[l - 1] + 3) / 4;
+        const size_t cubes = (size_t)ctx->lx[l] * ctx->ly[l] * ctx->lz[l];
+        VR_HIP(ctx, hipMalloc(&ctx->empty[l], ((cubes + 31) / 32) * sizeof(uint32_t)));
+    }
     ctx->occupancy_dirty = true;
     const unsigned brick_blocks = (unsigned)std::min<size_t>(ctx->brick_count, 1u << 20);
     hipLaunchKernelGGL((vr::k_build_bricks<T>), dim3(brick_blocks), dim3(256), 0, ctx->stream, (const T *)d_raw,
@@ -187,10 +193,12 @@ int refresh_occupancy(vr_ctx *ctx)
                        ctx->lut_info);
     const unsigned bricks = (unsigned)ctx->brick_count;
     hipLaunchKernelGGL(vr::k_classify_bricks, dim3((bricks + 255) / 256), dim3(256), 0, ctx->stream, ctx->cells, bricks, ctx->inv_hi,
-                       ctx->inv_lo, ctx->lut_info, ctx->empty_fine);
-    const unsigned cells = (unsigned)(ctx->ncx * ctx->ncy * ctx->ncz);
-    hipLaunchKernelGGL(vr::k_classify_coarse, dim3((cells + 255) / 256), dim3(256), 0, ctx->stream, ctx->empty_fine, ctx->nbx, ctx->nby,
-                       ctx->nbz, ctx->ncx, ctx->ncy, ctx->ncz, ctx->empty_coarse);
+                       ctx->inv_lo, ctx->lut_info, ctx->empty[0]);
+    for (int l = 1; l < vr::kLevels; l++) {
+        const unsigned cubes = (unsigned)(ctx->lx[l] * ctx->ly[l] * ctx->lz[l]);
+        hipLaunchKernelGGL(vr::k_classify_up, dim3((cubes + 255) / 256), dim3(256), 0, ctx->stream, ctx->empty[l - 1], ctx->lx[l - 1],
+                           ctx->ly[l - 1], ctx->lz[l - 1], ctx->lx[l], ctx->ly[l], ctx->lz[l], ctx->empty[l]);
+    }
     VR_HIP(ctx, hipGetLastError());
     ctx->occupancy_dirty = false;
     return VR_OK;
@@ -215,8 +223,10 @@ int rows_of_part(int rows, int part, int parts)
 template <typename T>
 void launch_frame(vr_ctx *ctx, const vr::FrameParams &fp, uint32_t *d_out, bool stats)
 {
-    const int tiles_x = (fp.x1 - fp.x0 + 15) / 16;
-    const dim3 grid((unsigned)(tiles_x * bands_of_part(fp.y1 - fp.y0, fp.part, fp.parts))), block(256);
+    // one wave per 8x8 tile; a band of 16 rows is two tile rows
+    const int tiles = ((fp.x1 - fp.x0 + 7) / 8) * 2 * bands_of_part(fp.y1 - fp.y0, fp.part, fp.parts);
+    const int waves_per_block = ctx->waves_per_block;
+    const dim3 grid((unsigned)((tiles + waves_per_block - 1) / waves_per_block)), block(64 * waves_per_block);
     const vr::VolumeView vol = view_of(ctx);
     const float4 border = make_float4(ctx->border[0], ctx->border[1], ctx->border[2], ctx->border[3]);
     const float4 *lut = reinterpret_cast<const float4 *>(ctx->lut);
@@ -226,27 +236,29 @@ void launch_frame(vr_ctx *ctx, const vr::FrameParams &fp, uint32_t *d_out, bool 
     (void)hipEventRecord(ctx->ring_a[slot], s);
     if (ctx->mode == VR_MODE_REFERENCE_ORDER) {
         if (stats)
-            hipLaunchKernelGGL((vr::k_march_exact<T, false, true, false>), grid, block, 0, s, vol, fp, lut, border, d_out, ctx->counters, ctx->touched, nullptr);
+            hipLaunchKernelGGL((vr::k_march_exact<T, false, true>), grid, block, 0, s, vol, fp, lut, border, d_out, ctx->counters, ctx->touched);
         else
-            hipLaunchKernelGGL((vr::k_march_exact<T, false, false, false>), grid, block, 0, s, vol, fp, lut, border, d_out, ctx->counters, ctx->touched, nullptr);
+            hipLaunchKernelGGL((vr::k_march_exact<T, false, false>), grid, block, 0, s, vol, fp, lut, border, d_out, ctx->counters, ctx->touched);
         (void)hipEventRecord(ctx->ring_b[slot], s);
     } else if (ctx->mode == VR_MODE_REFERENCE_SKIP) {
         if (stats)
-            hipLaunchKernelGGL((vr::k_march_exact<T, true, true, false>), grid, block, 0, s, vol, fp, lut, border, d_out, ctx->counters, ctx->touched, nullptr);
+            hipLaunchKernelGGL((vr::k_march_exact<T, true, true>), grid, block, 0, s, vol, fp, lut, border, d_out, ctx->counters, ctx->touched);
         else
-            hipLaunchKernelGGL((vr::k_march_exact<T, true, false, false>), grid, block, 0, s, vol, fp, lut, border, d_out, ctx->counters, ctx->touched, nullptr);
+            hipLaunchKernelGGL((vr::k_march_exact<T, true, false>), grid, block, 0, s, vol, fp, lut, border, d_out, ctx->counters, ctx->touched);
         (void)hipEventRecord(ctx->ring_b[slot], s);
     } else {
         // front-to-back march, then the rays it could not decide in reference order
-        const dim3 replay_grid(1024);
+        const dim3 replay_grid(2048);  // 8192 waves, one ray each per pass
         if (stats) {
-            hipLaunchKernelGGL((vr::k_march_fast<T, true>), grid, block, 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue);
+            hipLaunchKernelGGL((vr::k_march_fast<T, true>), grid, block, 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue, ctx->long_queue);
             (void)hipEventRecord(ctx->ring_b[slot], s);
-            hipLaunchKernelGGL((vr::k_march_exact<T, true, true, true>), replay_grid, block, 0, s, vol, fp, lut, border, d_out, ctx->counters, ctx->touched, ctx->queue);
+            hipLaunchKernelGGL((vr::k_march_long<T, true>), replay_grid, dim3(256), 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue, ctx->long_queue);
+            hipLaunchKernelGGL((vr::k_replay_exact<T, true>), replay_grid, dim3(256), 0, s, vol, fp, lut, border, d_out, ctx->counters, ctx->touched, ctx->queue);
         } else {
-            hipLaunchKernelGGL((vr::k_march_fast<T, false>), grid, block, 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue);
+            hipLaunchKernelGGL((vr::k_march_fast<T, false>), grid, block, 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue, ctx->long_queue);
             (void)hipEventRecord(ctx->ring_b[slot], s);
-            hipLaunchKernelGGL((vr::k_march_exact<T, true, false, true>), replay_grid, block, 0, s, vol, fp, lut, border, d_out, ctx->counters, ctx->touched, ctx->queue);
+            hipLaunchKernelGGL((vr::k_march_long<T, false>), replay_grid, dim3(256), 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue, ctx->long_queue);
+            hipLaunchKernelGGL((vr::k_replay_exact<T, false>), replay_grid, dim3(256), 0, s, vol, fp, lut, border, d_out, ctx->counters, ctx->touched, ctx->queue);
         }
     }
 }
@@ -274,6 +286,7 @@ int vr_create(int device, vr_ctx **out)
         vr_destroy(ctx);
         return VR_ERR_HIP;
     }
+    if (const char *e = std::getenv("VR_WAVES_PER_BLOCK")) ctx->waves_per_block = std::max(1, std::min(4, std::atoi(e)));
     ctx->ring_a.resize(vr_ctx::kRing, nullptr);
     ctx->ring_b.resize(vr_ctx::kRing, nullptr);
     for (int i = 0; i < vr_ctx::kRing; i++)
@@ -296,6 +309,7 @@ int vr_destroy(vr_ctx *ctx)
     if (ctx->counters) (void)hipFree(ctx->counters);
     if (ctx->frame) (void)hipFree(ctx->frame);
     if (ctx->queue) (void)hipFree(ctx->queue);
+    if (ctx->long_queue) (void)hipFree(ctx->long_queue);
     if (ctx->lut_info) (void)hipFree(ctx->lut_info);
     for (hipEvent_t e : ctx->ring_a)
         if (e) (void)hipEventDestroy(e);
@@ -578,15 +592,18 @@ static int render_impl(vr_ctx *ctx, int width, int height, int x0, int y0, int x
     const bool fast = ctx->mode == VR_MODE_FAST;
     if (fast && pixels > ctx->queue_cap) {
         if (ctx->queue) (void)hipFree(ctx->queue);
+        if (ctx->long_queue) (void)hipFree(ctx->long_queue);
         ctx->queue = nullptr;
+        ctx->long_queue = nullptr;
         ctx->queue_cap = 0;
         VR_HIP(ctx, hipMalloc(&ctx->queue, pixels * sizeof(uint32_t)));
+        VR_HIP(ctx, hipMalloc(&ctx->long_queue, pixels * sizeof(vr::LongRay)));
         ctx->queue_cap = pixels;
     }
     if (ctx->mode != VR_MODE_REFERENCE_ORDER)
         if (int rc = refresh_occupancy(ctx)) return rc;
     // the counters also carry the fast march's queue fill, so they are cleared every frame
-    VR_HIP(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(vr::Counters), ctx->stream));
+    VR_HIP(ctx, hipMemsetAsync(ctx->counters, 0, offsetof(vr::Counters, lut_error), ctx->stream));
     if (want_stats)
         VR_HIP(ctx, hipMemsetAsync(ctx->touched, 0, ((ctx->brick_count + 31) / 32) * sizeof(uint32_t), ctx->stream));
 
@@ -618,9 +635,12 @@ static int render_impl(vr_ctx *ctx, int width, int height, int x0, int y0, int x
         stats->cells_read = c.cells_read;
         stats->bricks_touched = touched;
         stats->replay_rays = c.replay_rays;
+        stats->long_rays = c.long_count;
         const uint64_t brick_bytes = (uint64_t)vr::kBrick * vr::kBrick * vr::kBrick * (uint64_t)ctx->dtype;
-        // bricks fetched + (fast/skip modes) one occupancy bit per brick and per supercell + LUT + frame
-        const uint64_t occupancy = ctx->mode == VR_MODE_REFERENCE_ORDER ? 0 : (ctx->brick_count + 7) / 8 + ((uint64_t)ctx->ncx * ctx->ncy * ctx->ncz + 7) / 8;
+        // bricks fetched + (fast/skip modes) the occupancy pyramid's bits + LUT + frame
+        uint64_t occupancy = 0;
+        if (ctx->mode != VR_MODE_REFERENCE_ORDER)
+            for (int l = 0; l < vr::kLevels; l++) occupancy += ((uint64_t)ctx->lx[l] * ctx->ly[l] * ctx->lz[l] + 7) / 8;
         stats->algorithmic_bytes = brick_bytes * touched + occupancy + (uint64_t)vr::kLutLds * 16ull + 4ull * pixels;
         float ms = 0.0f;
         VR_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
@@ -660,6 +680,18 @@ int vr_march_kernel_times(vr_ctx *ctx, float *ms, int capacity, int *count)
     return VR_OK;
 }
 
+#ifdef VR_DIAG
+// diagnostic build only (make diag): device buffer of 4 x uint64 per wave of the next fast march
+int vr_diag_set_timeline(vr_ctx *ctx, void *d_buffer)
+{
+    if (!ctx) return VR_ERR_ARG;
+    if (int rc = bind(ctx)) return rc;
+    VR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    VR_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(vr::g_vr_timeline), &d_buffer, sizeof d_buffer));
+    return VR_OK;
+}
+#endif
+
 int vr_band_rows(int height, int part, int parts)
 {
     if (height < 1 || parts < 1 || part < 0 || part >= parts) return VR_ERR_ARG;
@@ -681,9 +713,9 @@ int vr_count_hit_rays(vr_ctx *ctx, int width, int height, int x0, int y0, int x1
     fp.samples = ctx->samples;
     fp.part = 0;
     fp.parts = 1;
-    VR_HIP(ctx, hipMemsetAsync(ctx->counters, 0, sizeof(vr::Counters), ctx->stream));
-    const int tiles_x = (x1 - x0 + 15) / 16, tiles_y = (y1 - y0 + 15) / 16;
-    hipLaunchKernelGGL(vr::k_count_hits, dim3((unsigned)(tiles_x * tiles_y)), dim3(256), 0, ctx->stream, fp, &ctx->counters->rays_hit);
+    VR_HIP(ctx, hipMemsetAsync(ctx->counters, 0, offsetof(vr::Counters, lut_error), ctx->stream));
+    const int tiles = ((x1 - x0 + 7) / 8) * 2 * ((y1 - y0 + 15) / 16);
+    hipLaunchKernelGGL(vr::k_count_hits, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, ctx->stream, fp, &ctx->counters->rays_hit);
     unsigned long long h = 0;
     VR_HIP(ctx, hipMemcpyAsync(&h, &ctx->counters->rays_hit, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     VR_HIP(ctx, hipStreamSynchronize(ctx->stream));

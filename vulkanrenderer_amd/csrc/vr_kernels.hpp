@@ -34,12 +34,13 @@ struct VolumeView {
     float fx, fy, fz;       // (float) nx, ny, nz
     float inv_hi, inv_lo;   // 1/max split in two floats: v/max == fma(v, inv_hi, v*inv_lo) exactly
     float max_value;
-    // Occupancy for the current transfer function: one bit per brick / per 4^3-brick supercell,
-    // set when no tap whose low corner lies inside can receive a non-zero alpha.
-    const uint32_t *empty_fine;
-    const uint32_t *empty_coarse;
-    int ncx, ncy, ncz;      // supercells
+    // Occupancy pyramid for the current transfer function.  Level l has one bit per cube of
+    // (8 * 4^l)^3 padded voxels (level 0: a brick), set when no tap whose low corner lies inside
+    // can receive a non-zero alpha.  Grid of level l: lx[l] x ly[l] x lz[l] cubes.
+    const uint32_t *empty[4];
+    int lx[4], ly[4], lz[4];
 };
+constexpr int kLevels = 4;
 
 struct FrameParams {
     float m[16];      // toWorld, column-major (VolumeRendering.comp:20-22)
@@ -57,8 +58,11 @@ struct Counters {
     unsigned long long samples_evaluated;
     unsigned long long cells_read;
     unsigned long long replay_rays;
-    unsigned int replay_count;  // queue fill of the fast mode
+    unsigned int replay_count;  // fast mode: rays queued for the reference-order replay
+    unsigned int long_count;    // fast mode: rays handed from the lane march to the wave march
+    // everything above is cleared at the start of a frame; what follows persists
     unsigned int lut_error;
+    unsigned int pad_;
 };
 
 // LDS image of the transfer function: [0],[1] border, [2..257] the 256 texels, [258],[259] border.
@@ -234,20 +238,22 @@ __device__ __forceinline__ void stage_lut(float4 *s_lut, const float4 *lut, cons
     __syncthreads();
 }
 
-// Pixel owned by a lane: a block of 256 threads covers 16x16 pixels, wave w the 8x8 tile
-// (w & 1, w >> 1), lane l the pixel (l & 7, l >> 3) of it.
+// Pixel owned by a lane.  Every wave owns one 8x8 pixel tile (lane l the pixel (l & 7, l >> 3) of
+// it); tiles are numbered row-major over the rectangle's 8-row tile rows, one wave after the other
+// through the grid whatever the block size.
 // Returns false for lanes outside the rectangle.  out_index is the pixel's position in the output
 // buffer: rectangle rows, or with a sort-first split the rows of this part's bands, contiguous.
 __device__ __forceinline__ bool lane_pixel(const FrameParams &fp, int &px, int &py, uint32_t &out_index)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int tile = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     const int rect_w = fp.x1 - fp.x0;
-    const int tiles_x = (rect_w + 15) >> 4;
-    const int bx = blockIdx.x % tiles_x, band = blockIdx.x / tiles_x;   // band local to this part
-    const int row_in_band = (wave >> 1) * 8 + (lane >> 3);
-    px = fp.x0 + bx * 16 + (wave & 1) * 8 + (lane & 7);
-    py = fp.y0 + (band * fp.parts + fp.part) * 16 + row_in_band;
-    out_index = (uint32_t)((band * 16 + row_in_band) * rect_w + (px - fp.x0));
+    const int tiles_x = (rect_w + 7) >> 3;
+    const int tx = tile % tiles_x, trow = tile / tiles_x;     // trow: 8-row tile row local to this part
+    const int local_row = trow * 8 + (lane >> 3);             // row inside this part's dense output
+    px = fp.x0 + tx * 8 + (lane & 7);
+    py = fp.y0 + ((local_row >> 4) * fp.parts + fp.part) * 16 + (local_row & 15);
+    out_index = (uint32_t)(local_row * rect_w + (px - fp.x0));
     return px < fp.x1 && py < fp.y1;
 }
 

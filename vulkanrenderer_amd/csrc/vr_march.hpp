@@ -11,6 +11,10 @@
 
 namespace vr {
 
+#ifdef VR_DIAG
+__device__ unsigned long long *g_vr_timeline = nullptr;
+#endif
+
 // ---- what the marches need to know about the current transfer function ----------------------
 struct LutInfo {
     // bad_prefix[i]: number of entries j < i of the 260-entry LDS table (kLutLds) that are "bad"
@@ -94,12 +98,21 @@ __device__ __forceinline__ void tf_entry_range(float lo, float hi, int &first, i
     last = last > kLutLds - 1 ? kLutLds - 1 : last;
 }
 
-// One bit per brick: set when the transfer function is exactly transparent (and finite) over the
-// whole value range of the brick's 9^3 voxels, i.e. for every tap whose filter footprint comes
-// from this brick.
+__device__ __forceinline__ void store_ballot(bool flag, uint32_t first_item, uint32_t item_count, uint32_t *bits)
+{
+    const unsigned long long mask = __ballot(flag);
+    const int lane = threadIdx.x & 63;
+    const uint32_t word = first_item >> 5;  // first_item is a multiple of 64
+    if (lane == 0 && word * 32u < item_count) bits[word] = (uint32_t)mask;
+    if (lane == 32 && (word + 1) * 32u < item_count) bits[word + 1] = (uint32_t)(mask >> 32);
+}
+
+// Level 0 of the occupancy pyramid: a brick is empty when the transfer function is exactly
+// transparent (and finite) over the whole value range of its 9^3 voxels, i.e. for every tap whose
+// filter footprint comes from this brick.
 __global__ __launch_bounds__(256) void k_classify_bricks(const uint32_t *__restrict__ cells, uint32_t brick_count,
                                                         float inv_hi, float inv_lo, const LutInfo *__restrict__ info,
-                                                        uint32_t *__restrict__ empty_fine)
+                                                        uint32_t *__restrict__ empty0)
 {
     const uint32_t b = blockIdx.x * 256u + threadIdx.x;
     bool empty = false;
@@ -110,226 +123,300 @@ __global__ __launch_bounds__(256) void k_classify_bricks(const uint32_t *__restr
         tf_entry_range(__builtin_fmaf(lo, inv_hi, lo * inv_lo), __builtin_fmaf(hi, inv_hi, hi * inv_lo), first, last);
         empty = info->bad_prefix[last + 1] == info->bad_prefix[first];
     }
-    const unsigned long long mask = __ballot(empty);
-    const int lane = threadIdx.x & 63;
-    const uint32_t word = (blockIdx.x * 256u + (threadIdx.x & ~63u)) >> 5;
-    if (lane == 0 && word * 32u < brick_count) empty_fine[word] = (uint32_t)mask;
-    if (lane == 32 && (word + 1) * 32u < brick_count) empty_fine[word + 1] = (uint32_t)(mask >> 32);
+    store_ballot(empty, blockIdx.x * 256u + (threadIdx.x & ~63u), brick_count, empty0);
 }
 
-// One bit per supercell of 4^3 bricks: set when all of its bricks inside the grid are empty.
-__global__ __launch_bounds__(256) void k_classify_coarse(const uint32_t *__restrict__ empty_fine, int nbx, int nby, int nbz,
-                                                        int ncx, int ncy, int ncz, uint32_t *__restrict__ empty_coarse)
+// Level l+1 from level l: a cube is empty when its (up to) 4^3 children inside the grid are.
+__global__ __launch_bounds__(256) void k_classify_up(const uint32_t *__restrict__ child, int cnx, int cny, int cnz, int px,
+                                                    int py, int pz, uint32_t *__restrict__ parent)
 {
-    const uint32_t sc = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t count = (uint32_t)(ncx * ncy * ncz);
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t count = (uint32_t)(px * py * pz);
     bool empty = false;
-    if (sc < count) {
-        const int cx = sc % ncx, cy = (sc / ncx) % ncy, cz = sc / (ncx * ncy);
+    if (p < count) {
+        const int x = p % px, y = (p / px) % py, z = p / (px * py);
         empty = true;
         for (int dz = 0; dz < 4 && empty; dz++)
             for (int dy = 0; dy < 4 && empty; dy++) {
-                const int bz = cz * 4 + dz, by = cy * 4 + dy;
-                if (bz >= nbz || by >= nby) continue;
+                const int cz = z * 4 + dz, cy = y * 4 + dy;
+                if (cz >= cnz || cy >= cny) continue;
                 for (int dx = 0; dx < 4; dx++) {
-                    const int bx = cx * 4 + dx;
-                    if (bx >= nbx) continue;
-                    const uint32_t b = (uint32_t)((bz * nby + by) * nbx + bx);
-                    if (!((empty_fine[b >> 5] >> (b & 31)) & 1u)) empty = false;
+                    const int cx = x * 4 + dx;
+                    if (cx >= cnx) continue;
+                    const uint32_t c = (uint32_t)((cz * cny + cy) * cnx + cx);
+                    if (!((child[c >> 5] >> (c & 31)) & 1u)) empty = false;
                 }
             }
     }
-    const unsigned long long mask = __ballot(empty);
-    const int lane = threadIdx.x & 63;
-    const uint32_t word = (blockIdx.x * 256u + (threadIdx.x & ~63u)) >> 5;
-    if (lane == 0 && word * 32u < count) empty_coarse[word] = (uint32_t)mask;
-    if (lane == 32 && (word + 1) * 32u < count) empty_coarse[word + 1] = (uint32_t)(mask >> 32);
+    store_ballot(empty, blockIdx.x * 256u + (threadIdx.x & ~63u), count, parent);
 }
 
 // ---- stepping over empty space ----------------------------------------------------------------
-// Along a ray the padded texel coordinate g = u*size - 0.5 + kPad is linear in the tap index.
-// dir holds its change per march step; inv the reciprocals.  steps_inside() returns how many
-// consecutive taps, starting with the current one, are certain to have their low corner in the
-// axis-aligned region [lo, lo + extent)^3: the region is shrunk by `margin` texels on every
-// side, far more than the rounding difference between this linear model and the positions the
-// taps really get, so the count never includes a tap outside the region.
-struct MarchDir {
-    float dx, dy, dz;
-    float ix, iy, iz;
+// Along a ray the padded texel coordinate G = u*size - 0.5 + kPad is, in real arithmetic, linear
+// in the tap index t: G(t) = a + t*b.  The marches walk this line model to find empty regions and
+// to count how many taps lie in them; taps that are fetched always get their exact position.
+// The model and the exact float position of a tap differ only by rounding (a few 1e-3 texels for
+// a 2048^3 volume), so every test against a region is made against the region shrunk by `margin`
+// texels on each side: a tap whose model position is inside the shrunk region has its true low
+// corner inside the region.
+struct RayModel {
+    float ax, ay, az;
+    float bx, by, bz;
     float margin;
 };
 
-__device__ __forceinline__ MarchDir march_dir(const Ray &r, const VolumeView &v, float step, float sign)
+__device__ __forceinline__ RayModel ray_model(const Ray &r, const VolumeView &v, float step)
 {
-    MarchDir m;
-    // one step towards the eye (tap index - 1) moves the position by +step*d; u = x + .5,
-    // v = y + .5, w = -z inside the box (VolumeRendering.comp:168,187)
-    m.dx = sign * (step * r.d[0] * v.fx);
-    m.dy = sign * (step * r.d[1] * v.fy);
-    m.dz = sign * -(step * r.d[2] * v.fz);
-    m.ix = m.dx != 0.0f ? 1.0f / m.dx : 0.0f;
-    m.iy = m.dy != 0.0f ? 1.0f / m.dy : 0.0f;
-    m.iz = m.dz != 0.0f ? 1.0f / m.dz : 0.0f;
+    RayModel m;
+    // world(t) = o + (tmax - t*step)*d; u = x + .5, v = y + .5, w = -z inside the box
+    // (VolumeRendering.comp:168,187)
+    m.ax = (r.o[0] + r.tmax * r.d[0] + 0.5f) * v.fx - 0.5f + (float)kPad;
+    m.ay = (r.o[1] + r.tmax * r.d[1] + 0.5f) * v.fy - 0.5f + (float)kPad;
+    m.az = -(r.o[2] + r.tmax * r.d[2]) * v.fz - 0.5f + (float)kPad;
+    m.bx = -(step * r.d[0]) * v.fx;
+    m.by = -(step * r.d[1]) * v.fy;
+    m.bz = (step * r.d[2]) * v.fz;
     const float big = fmaxf(v.fx, fmaxf(v.fy, v.fz));
     m.margin = fmaxf(0.02f, big * 1e-5f);
     return m;
 }
 
-__device__ __forceinline__ float axis_steps(float g, float lo, float extent, float d, float inv, float margin)
+// Taps t, t + dir, t + 2*dir, ... (dir = +1 or -1) whose model position stays inside the cube
+// [lo, lo + extent)^3 shrunk by the margin; 0 when tap t itself is not inside.
+__device__ __forceinline__ float axis_span(float g, float lo, float extent, float d, float margin)
 {
-    if (d > 0.0f) return (lo + extent - margin - g) * inv;
-    if (d < 0.0f) return (lo + margin - g) * inv;
+    const float a = lo + margin, b = lo + extent - margin;
+    if (!(g >= a && g <= b)) return -1.0f;
+    if (d > 0.0f) return (b - g) / d;
+    if (d < 0.0f) return (a - g) / d;
     return 1e9f;
 }
 
-__device__ __forceinline__ int steps_inside(const Tap &p, int lox, int loy, int loz, float extent, const MarchDir &m)
+__device__ __forceinline__ int span_inside(float gx, float gy, float gz, int lox, int loy, int loz, float extent,
+                                           const RayModel &m, float dir)
 {
-    float n = axis_steps(p.x + (float)kPad, (float)lox, extent, m.dx, m.ix, m.margin);
-    n = fminf(n, axis_steps(p.y + (float)kPad, (float)loy, extent, m.dy, m.iy, m.margin));
-    n = fminf(n, axis_steps(p.z + (float)kPad, (float)loz, extent, m.dz, m.iz, m.margin));
-    n = fminf(n, 1e9f);
-    return 1 + ((n > 0.0f) ? (int)n : 0);
+    float n = axis_span(gx, (float)lox, extent, dir * m.bx, m.margin);
+    n = fminf(n, axis_span(gy, (float)loy, extent, dir * m.by, m.margin));
+    n = fminf(n, axis_span(gz, (float)loz, extent, dir * m.bz, m.margin));
+    if (!(n >= 0.0f)) return 0;
+    return 1 + (int)fminf(n, 1e9f);
 }
 
-__device__ __forceinline__ bool coarse_empty(const Cell &c, const VolumeView &v)
+// Coarsest empty pyramid level that contains brick (cx, cy, cz), or -1.  The four words are
+// independent loads, so they are in flight together.
+__device__ __forceinline__ int empty_level(const VolumeView &v, int cx, int cy, int cz)
 {
-    const uint32_t sc = (uint32_t)(((c.sz >> 5) * v.ncy + (c.sy >> 5)) * v.ncx + (c.sx >> 5));
-    return (v.empty_coarse[sc >> 5] >> (sc & 31)) & 1u;
+    uint32_t bit[kLevels];
+#pragma unroll
+    for (int l = 0; l < kLevels; l++) {
+        const uint32_t i = (uint32_t)((((cz >> (2 * l)) * v.ly[l]) + (cy >> (2 * l))) * v.lx[l] + (cx >> (2 * l)));
+        bit[l] = (v.empty[l][i >> 5] >> (i & 31)) & 1u;
+    }
+    int level = -1;
+#pragma unroll
+    for (int l = 0; l < kLevels; l++)
+        if (bit[l]) level = l;
+    return level;
 }
 
-__device__ __forceinline__ bool fine_empty(uint32_t brick, const VolumeView &v)
+__device__ __forceinline__ bool brick_empty(uint32_t brick, const VolumeView &v)
 {
-    return (v.empty_fine[brick >> 5] >> (brick & 31)) & 1u;
+    return (v.empty[0][brick >> 5] >> (brick & 31)) & 1u;
+}
+
+// How many taps, starting at t and walking in direction dir, can be stepped over because the line
+// model puts them inside an empty cube of the pyramid.  0: tap t needs an exact look.
+__device__ __forceinline__ int empty_span(const VolumeView &v, const RayModel &m, int t, float dir)
+{
+    const float ft = (float)t;
+    const float gx = __builtin_fmaf(ft, m.bx, m.ax), gy = __builtin_fmaf(ft, m.by, m.ay), gz = __builtin_fmaf(ft, m.bz, m.az);
+    int cx = (int)fminf(fmaxf(gx, 0.0f), 1e7f) >> 3;
+    int cy = (int)fminf(fmaxf(gy, 0.0f), 1e7f) >> 3;
+    int cz = (int)fminf(fmaxf(gz, 0.0f), 1e7f) >> 3;
+    cx = cx < v.lx[0] ? cx : v.lx[0] - 1;
+    cy = cy < v.ly[0] ? cy : v.ly[0] - 1;
+    cz = cz < v.lz[0] ? cz : v.lz[0] - 1;
+    const int level = empty_level(v, cx, cy, cz);
+    if (level < 0) return 0;
+    const int shift = 3 + 2 * level;
+    return span_inside(gx, gy, gz, (cx >> (2 * level)) << shift, (cy >> (2 * level)) << shift, (cz >> (2 * level)) << shift,
+                       (float)(1 << shift), m, dir);
+}
+
+// The same count when the tap's exact brick (cx, cy, cz) is already known to lie in an empty cube of
+// pyramid level `level`: taps t, t + dir, ... whose model position stays inside that cube.
+__device__ __forceinline__ int empty_span_at(const VolumeView &v, const RayModel &m, int t, float dir, int level, int cx,
+                                             int cy, int cz)
+{
+    const float ft = (float)t;
+    const float gx = __builtin_fmaf(ft, m.bx, m.ax), gy = __builtin_fmaf(ft, m.by, m.ay), gz = __builtin_fmaf(ft, m.bz, m.az);
+    const int shift = 3 + 2 * level;
+    return span_inside(gx, gy, gz, (cx >> (2 * level)) << shift, (cy >> (2 * level)) << shift, (cz >> (2 * level)) << shift,
+                       (float)(1 << shift), m, dir);
 }
 
 // ---- reference-order march ---------------------------------------------------------------------
 // Back to front over the samples + 2 taps exactly as the shader loops (VolumeRendering.comp:
-// 183-202), same blend expression, so the colour is bit-identical to it.  With SKIP, a tap whose
-// brick (or supercell) is marked empty is not fetched: its alpha is exactly 0 and the blend
-// a*c + (1-a)*C leaves C unchanged bit for bit.  The back-most tap (t == 0) is always fetched
-// because the shader assigns its colour instead of blending.
-// With QUEUE the kernel marches the pixels listed in `queue` (count in ctr->replay_count) instead
-// of a rectangle; the fast march uses this to re-do rays whose byte it could not decide.
-template <typename T, bool SKIP, bool STATS, bool QUEUE>
+// 183-202), same blend expression, so the colour is bit-identical to it.  With SKIP, a tap that
+// lies in an empty cube of the occupancy pyramid is not fetched: its alpha is exactly 0 and the
+// blend a*c + (1-a)*C leaves C unchanged bit for bit.  The back-most tap (t == 0) is always
+// fetched because the shader assigns its colour instead of blending.
+template <typename T, bool SKIP, bool STATS>
 __global__ __launch_bounds__(256) void k_march_exact(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
                                                     float4 border, uint32_t *__restrict__ out, Counters *ctr,
-                                                    uint32_t *touched, const uint32_t *__restrict__ queue)
-{
-    __shared__ float4 s_lut[kLutLds];
-    stage_lut(s_lut, lut, border);
-    uint32_t entry = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t stride = gridDim.x * 256u;
-    const uint32_t entries = QUEUE ? ctr->replay_count : 1u;
-    for (; QUEUE ? entry < entries : true; entry += stride) {
-        int px, py;
-        uint32_t out_index;
-        if (QUEUE) {
-            out_index = queue[entry];
-            pixel_of_index(fp, out_index, px, py);
-        } else {
-            if (!lane_pixel(fp, px, py, out_index)) return;
-        }
-        const Ray r = make_ray(fp, px, py);
-        float cr = 0.0f, cg = 0.0f, cb = 0.0f;
-        unsigned long long evaluated = 0, lookups = 0;
-        if (r.hit) {
-            const int last = fp.samples + 1;
-            const float step = (r.tmax - r.tmin) / (float)(uint32_t)last;
-            const MarchDir md = march_dir(r, vol, step, -1.0f);
-            int t = 0;
-            while (t <= last) {
-                const Tap p = tap_position(r, vol, step, t);
-                const Cell c = tap_cell(p, vol);
-                const uint32_t brick = brick_of(c, vol);
-                if (SKIP && t > 0) {
-                    if (STATS) lookups++;
-                    if (coarse_empty(c, vol)) {
-                        t += steps_inside(p, c.sx & ~31, c.sy & ~31, c.sz & ~31, 32.0f, md);
-                        continue;
-                    }
-                    if (fine_empty(brick, vol)) {
-                        t += steps_inside(p, c.sx & ~7, c.sy & ~7, c.sz & ~7, 8.0f, md);
-                        continue;
-                    }
-                }
-                const float inten = sample_volume<T>(c, brick, vol);
-                const float4 tf = sample_tf(s_lut, inten);
-                if (t == 0) {
-                    cr = tf.x; cg = tf.y; cb = tf.z;
-                } else {
-                    const float a = tf.w, ia = 1.0f - tf.w;
-                    cr = a * tf.x + ia * cr;
-                    cg = a * tf.y + ia * cg;
-                    cb = a * tf.z + ia * cb;
-                }
-                if (STATS) {
-                    evaluated++;
-                    atomicOr(&touched[brick >> 5], 1u << (brick & 31));
-                }
-                t++;
-            }
-        }
-        out[out_index] = pack_rgba8(cr, cg, cb);
-        if (STATS) {
-            if (!QUEUE) atomicAdd(&ctr->rays_hit, r.hit ? 1ull : 0ull);
-            if (QUEUE) atomicAdd(&ctr->replay_rays, 1ull);
-            atomicAdd(&ctr->samples_evaluated, evaluated);
-            atomicAdd(&ctr->cells_read, lookups);
-        }
-        if (!QUEUE) break;
-    }
-}
-
-// ---- front-to-back march ------------------------------------------------------------------------
-// Visits the taps from the eye towards the back, steps over empty bricks and supercells, and
-// stops a ray as soon as its RGBA8 value is decided.
-//
-// The shader's result for a ray is C = sum_t Tf(t) a_t c_t + Tf(0) c_0 with Tf(t) the product of
-// (1 - a_s) over the taps s in front of t, evaluated back to front in float.  This kernel
-// accumulates F = sum over the visited taps and the transmittance Tr in double (exact for this
-// purpose) and keeps, per channel, an interval that must contain the shader's float result:
-//     [F + Tr*cmin - E,  F + Tr*cmax + E],   E = kappa * (S + Tr * taps_left),
-// where the taps not yet visited contribute Tr times a weighted mean of colours in [cmin,cmax]
-// (alphas lie in [0,1]), S is the sum of Tr over the visited taps with a != 0 and kappa bounds
-// the rounding error one float blend step adds (attenuated by everything in front of it; steps
-// with a == 0 are exact).  float -> unorm8 is monotone, so when both interval ends convert to the
-// same byte in all three channels the pixel is final.  A ray whose bytes are still undecided at
-// the back tap is appended to a queue and re-marched in reference order by k_march_exact.
-// The loop leaves a wave when no lane has a tap left: lanes first step over empty space
-// (cheap, divergent), then all lanes that found a tap fetch it together.
-template <typename T, bool STATS>
-__global__ __launch_bounds__(256) void k_march_fast(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
-                                                   float4 border, const LutInfo *__restrict__ info,
-                                                   uint32_t *__restrict__ out, Counters *ctr, uint32_t *touched,
-                                                   uint32_t *__restrict__ queue)
+                                                    uint32_t *touched)
 {
     __shared__ float4 s_lut[kLutLds];
     stage_lut(s_lut, lut, border);
     int px, py;
-    uint32_t pixel_id;
-    const bool in_rect = lane_pixel(fp, px, py, pixel_id);
-
-    const Ray r = make_ray(fp, in_rect ? px : fp.x0, in_rect ? py : fp.y0);
-    const bool fast_ok = info->fast_ok != 0;
-    const float cmin[3] = {info->cmin[0], info->cmin[1], info->cmin[2]};
-    const float cmax[3] = {info->cmax[0], info->cmax[1], info->cmax[2]};
-    const float kappa[3] = {info->kappa[0], info->kappa[1], info->kappa[2]};
-
-    const int last = fp.samples + 1;
-    const float step = (r.tmax - r.tmin) / (float)(uint32_t)last;
-    const MarchDir md = march_dir(r, vol, step, 1.0f);
-
-    double F0 = 0.0, F1 = 0.0, F2 = 0.0, Tr = 1.0;
-    float S = 0.0f;
-    int t = last;                       // front-most tap
-    bool marching = in_rect && r.hit;   // still has taps with index >= 1 to visit
-    bool decided = false;
-    uint32_t rgba = 0xff000000u;        // miss: clear colour (VolumeRendering.comp:174,180)
+    uint32_t out_index;
+    if (!lane_pixel(fp, px, py, out_index)) return;
+    const Ray r = make_ray(fp, px, py);
+    float cr = 0.0f, cg = 0.0f, cb = 0.0f;
     unsigned long long evaluated = 0, lookups = 0;
+    if (r.hit) {
+        const int last = fp.samples + 1;
+        const float step = (r.tmax - r.tmin) / (float)(uint32_t)last;
+        const RayModel rm = ray_model(r, vol, step);
+        int t = 0;
+        while (t <= last) {
+            if (SKIP && t > 0) {
+                if (STATS) lookups++;
+                const int n = empty_span(vol, rm, t, 1.0f);
+                if (n > 0) {
+                    t += n;
+                    continue;
+                }
+            }
+            const Tap p = tap_position(r, vol, step, t);
+            const Cell c = tap_cell(p, vol);
+            const uint32_t brick = brick_of(c, vol);
+            if (SKIP && t > 0 && brick_empty(brick, vol)) {
+                t++;
+                continue;
+            }
+            const float inten = sample_volume<T>(c, brick, vol);
+            const float4 tf = sample_tf(s_lut, inten);
+            if (t == 0) {
+                cr = tf.x; cg = tf.y; cb = tf.z;
+            } else {
+                const float a = tf.w, ia = 1.0f - tf.w;
+                cr = a * tf.x + ia * cr;
+                cg = a * tf.y + ia * cg;
+                cb = a * tf.z + ia * cb;
+            }
+            if (STATS) {
+                evaluated++;
+                atomicOr(&touched[brick >> 5], 1u << (brick & 31));
+            }
+            t++;
+        }
+    }
+    out[out_index] = pack_rgba8(cr, cg, cb);
+    if (STATS) {
+        atomicAdd(&ctr->rays_hit, r.hit ? 1ull : 0ull);
+        atomicAdd(&ctr->samples_evaluated, evaluated);
+        atomicAdd(&ctr->cells_read, lookups);
+    }
+}
 
-    // is the byte of every channel fixed, given the taps still to come?
-    auto try_decide = [&](int taps_left) -> bool {
-        const double tr = Tr;
+// Reference-order march of the rays listed in `queue` (count in ctr->replay_count), one wave per
+// ray: the fast march hands over the few rays whose bytes it could not decide, far too few to
+// fill the chip with one lane each.  The 64 lanes fetch 64 consecutive taps at once; the blend
+// itself is inherently serial, so the lanes' (alpha, colour) are then folded in tap order with
+// the shader's expression.  Taps with alpha exactly 0 and a finite colour are identities and are
+// left out of the fold; the back-most tap assigns.
+template <typename T, bool STATS>
+__global__ __launch_bounds__(256) void k_replay_exact(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
+                                                     float4 border, uint32_t *__restrict__ out, Counters *ctr,
+                                                     uint32_t *touched, const uint32_t *__restrict__ queue)
+{
+    __shared__ float4 s_lut[kLutLds];
+    stage_lut(s_lut, lut, border);
+    const int lane = threadIdx.x & 63;
+    const uint32_t waves = gridDim.x * 4u;
+    const uint32_t entries = ctr->replay_count;
+    for (uint32_t entry = blockIdx.x * 4u + (threadIdx.x >> 6); entry < entries; entry += waves) {
+        const uint32_t out_index = queue[entry];
+        int px, py;
+        pixel_of_index(fp, out_index, px, py);
+        const Ray r = make_ray(fp, px, py);          // identical in every lane
+        const int last = fp.samples + 1;
+        const float step = (r.tmax - r.tmin) / (float)(uint32_t)last;
+        const RayModel rm = ray_model(r, vol, step);
+        float cr = 0.0f, cg = 0.0f, cb = 0.0f;
+        unsigned long long evaluated = 0;
+        int base = 0;
+        while (base <= last) {
+            if (base > 0) {
+                const int n = empty_span(vol, rm, base, 1.0f);   // wave-uniform: whole runs of empty taps
+                if (n > 0) {
+                    base += n;
+                    continue;
+                }
+            }
+            const int t = base + lane;
+            bool fetch = t <= last;
+            Cell c;
+            uint32_t brick = 0;
+            if (fetch) {
+                const Tap p = tap_position(r, vol, step, t);
+                c = tap_cell(p, vol);
+                brick = brick_of(c, vol);
+                if (t > 0 && brick_empty(brick, vol)) fetch = false;
+            }
+            float4 tf = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (fetch) {
+                tf = sample_tf(s_lut, sample_volume<T>(c, brick, vol));
+                if (STATS) {
+                    evaluated++;
+                    atomicOr(&touched[brick >> 5], 1u << (brick & 31));
+                }
+            }
+            const bool identity = tf.w == 0.0f && isfinite(tf.x) && isfinite(tf.y) && isfinite(tf.z);
+            unsigned long long todo = __ballot(fetch && (t == 0 || !identity));
+            while (todo) {
+                const int src = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const float a = __shfl(tf.w, src), x = __shfl(tf.x, src), y = __shfl(tf.y, src), z = __shfl(tf.z, src);
+                if (base + src == 0) {
+                    cr = x; cg = y; cb = z;
+                } else {
+                    const float ia = 1.0f - a;
+                    cr = a * x + ia * cr;
+                    cg = a * y + ia * cg;
+                    cb = a * z + ia * cb;
+                }
+            }
+            base += 64;
+        }
+        if (!r.hit) { cr = cg = cb = 0.0f; }
+        if (lane == 0) out[out_index] = pack_rgba8(cr, cg, cb);
+        if (STATS) {
+            if (lane == 0) atomicAdd(&ctr->replay_rays, 1ull);
+            atomicAdd(&ctr->samples_evaluated, evaluated);
+        }
+    }
+}
+
+// ---- deciding a pixel before the ray is finished -------------------------------------------------
+// See k_march_fast for the argument.  decide() returns true and the final bytes when, for all
+// three channels, both ends of the interval that must contain the shader's float result convert to
+// the same unorm8 value.
+struct Decider {
+    float cmin[3], cmax[3], kappa[3];
+    bool ok;
+    __device__ explicit Decider(const LutInfo *info)
+    {
+        for (int c = 0; c < 3; c++) {
+            cmin[c] = info->cmin[c];
+            cmax[c] = info->cmax[c];
+            kappa[c] = info->kappa[c];
+        }
+        ok = info->fast_ok != 0;
+    }
+    __device__ __forceinline__ bool decide(double F0, double F1, double F2, double tr, float S, int taps_left, uint32_t &rgba) const
+    {
         const float spread = S * 1.001f + (float)tr * (float)taps_left;
         uint32_t bytes = 0xff000000u;
         bool same = true;
@@ -347,9 +434,76 @@ __global__ __launch_bounds__(256) void k_march_fast(VolumeView vol, FrameParams 
         }
         if (same) rgba = bytes;
         return same;
-    };
+    }
+};
 
-    while (true) {
+// A ray the lane-per-ray march hands over to a whole wave: where it stands and what it has
+// accumulated (k_march_fast -> k_march_long).
+struct LongRay {
+    uint32_t pixel_id;
+    int t;        // next tap to visit (>= 1)
+    float S;
+    float pad_;
+    double F0, F1, F2, Tr;
+};
+
+// Fetch rounds a lane spends on its ray before it hands the rest over: bounds the serial,
+// latency-bound chain a single slow ray (one that grazes the object without ever becoming opaque)
+// can keep its wave alive for.
+constexpr int kLaneBudget = 64;
+
+// ---- front-to-back march ------------------------------------------------------------------------
+// Visits the taps from the eye towards the back, steps over empty cubes of the occupancy pyramid,
+// and stops a ray as soon as its RGBA8 value is decided.
+//
+// The shader's result for a ray is C = sum_t Tf(t) a_t c_t + Tf(0) c_0 with Tf(t) the product of
+// (1 - a_s) over the taps s in front of t, evaluated back to front in float.  This kernel
+// accumulates F = sum over the visited taps and the transmittance Tr in double (exact for this
+// purpose) and keeps, per channel, an interval that must contain the shader's float result:
+//     [F + Tr*cmin - E,  F + Tr*cmax + E],   E = kappa * (S + Tr * taps_left),
+// where the taps not yet visited contribute Tr times a weighted mean of colours in [cmin,cmax]
+// (alphas lie in [0,1]), S is the sum of Tr over the visited taps with a != 0 and kappa bounds
+// the rounding error one float blend step adds (attenuated by everything in front of it; steps
+// with a == 0 are exact).  float -> unorm8 is monotone, so when both interval ends convert to the
+// same byte in all three channels the pixel is final.  A ray whose bytes are still undecided at
+// the back tap is appended to a queue and re-marched in reference order by k_replay_exact.
+// The loop leaves a wave when no lane has a tap left (wavefront ballot): lanes first step over
+// empty space (cheap, divergent), then all lanes that found a tap fetch it together.
+template <typename T, bool STATS>
+__global__ __launch_bounds__(256) void k_march_fast(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
+                                                   float4 border, const LutInfo *__restrict__ info,
+                                                   uint32_t *__restrict__ out, Counters *ctr, uint32_t *touched,
+                                                   uint32_t *__restrict__ queue, LongRay *__restrict__ long_queue)
+{
+    __shared__ float4 s_lut[kLutLds];
+#ifdef VR_DIAG
+    const unsigned long long diag_t0 = wall_clock64();
+#endif
+    stage_lut(s_lut, lut, border);
+    int px, py;
+    uint32_t pixel_id;
+    const bool in_rect = lane_pixel(fp, px, py, pixel_id);
+
+    const Ray r = make_ray(fp, in_rect ? px : fp.x0, in_rect ? py : fp.y0);
+    const Decider dec(info);
+    const bool fast_ok = dec.ok;
+
+    const int last = fp.samples + 1;
+    const float step = (r.tmax - r.tmin) / (float)(uint32_t)last;
+    const RayModel rm = ray_model(r, vol, step);
+
+    double F0 = 0.0, F1 = 0.0, F2 = 0.0, Tr = 1.0;
+    float S = 0.0f;
+    int t = last;                       // front-most tap
+    bool marching = in_rect && r.hit;   // still has taps with index >= 1 to visit
+    bool decided = false;
+    uint32_t rgba = 0xff000000u;        // miss: clear colour (VolumeRendering.comp:174,180)
+    unsigned long long evaluated = 0, lookups = 0;
+
+    auto try_decide = [&](int taps_left) -> bool { return dec.decide(F0, F1, F2, Tr, S, taps_left, rgba); };
+
+    uint32_t solid = 0xffffffffu;       // last brick found occupied: its taps need no occupancy lookup
+    for (int round = 0; round < kLaneBudget; round++) {
         // 1. step over empty space until this lane stands on a tap that must be fetched
         bool have = false;
         Cell c;
@@ -359,14 +513,18 @@ __global__ __launch_bounds__(256) void k_march_fast(VolumeView vol, FrameParams 
             const Tap p = tap_position(r, vol, step, t);
             c = tap_cell(p, vol);
             brick = brick_of(c, vol);
+            if (brick == solid) { have = true; break; }
             if (STATS) lookups++;
-            if (coarse_empty(c, vol)) {
-                t -= steps_inside(p, c.sx & ~31, c.sy & ~31, c.sz & ~31, 32.0f, md);
-            } else if (fine_empty(brick, vol)) {
-                t -= steps_inside(p, c.sx & ~7, c.sy & ~7, c.sz & ~7, 8.0f, md);
-            } else {
+            const int level = empty_level(vol, c.sx >> 3, c.sy >> 3, c.sz >> 3);
+            if (level < 0) {
+                solid = brick;
                 have = true;
+                break;
             }
+            // tap t is in an empty cube for certain (exact cell); the line model says how many of
+            // the following taps are too
+            const int n = empty_span_at(vol, rm, t, -1.0f, level, c.sx >> 3, c.sy >> 3, c.sz >> 3);
+            t -= n > 1 ? n : 1;
         }
         // 2. the wave leaves the loop when no lane has a tap to fetch
         if (__ballot(have) == 0ull) break;
@@ -395,7 +553,13 @@ __global__ __launch_bounds__(256) void k_march_fast(VolumeView vol, FrameParams 
         }
     }
 
-    if (in_rect) {
+    if (marching) {
+        // out of budget with taps left: a wave continues this ray (k_march_long)
+        LongRay e;
+        e.pixel_id = pixel_id; e.t = t; e.S = S; e.pad_ = 0.0f;
+        e.F0 = F0; e.F1 = F1; e.F2 = F2; e.Tr = Tr;
+        long_queue[atomicAdd(&ctr->long_count, 1u)] = e;
+    } else if (in_rect) {
         if (r.hit && !decided) {
             // back-most tap: its colour enters unweighted by its alpha (VolumeRendering.comp:189-191)
             const Tap p = tap_position(r, vol, step, 0);
@@ -414,22 +578,133 @@ __global__ __launch_bounds__(256) void k_march_fast(VolumeView vol, FrameParams 
             if (!decided) queue[atomicAdd(&ctr->replay_count, 1u)] = pixel_id;
         }
         if (!r.hit || decided) out[pixel_id] = rgba;
-        if (STATS) {
-            atomicAdd(&ctr->rays_hit, r.hit ? 1ull : 0ull);
-            atomicAdd(&ctr->samples_evaluated, evaluated);
-            atomicAdd(&ctr->cells_read, lookups);
+    }
+    if (STATS && in_rect) {
+        atomicAdd(&ctr->rays_hit, r.hit ? 1ull : 0ull);
+        atomicAdd(&ctr->samples_evaluated, evaluated);
+        atomicAdd(&ctr->cells_read, lookups);
+    }
+#ifdef VR_DIAG
+    // diagnostic build only: wave start/end wall clock (100 MHz) and placement, one record per wave
+    if (g_vr_timeline && (threadIdx.x & 63) == 0) {
+        const unsigned long long wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        unsigned int hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned int xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_vr_timeline[wave_id * 4 + 0] = diag_t0;
+        g_vr_timeline[wave_id * 4 + 1] = wall_clock64();
+        g_vr_timeline[wave_id * 4 + 2] = ((unsigned long long)xcc << 32) | hw;
+        g_vr_timeline[wave_id * 4 + 3] = 0;
+    }
+#endif
+}
+
+// Continuation of the rays k_march_fast ran out of budget on, one wave per ray.  The 64 lanes
+// fetch 64 consecutive taps at once (or the whole wave steps over an empty cube), then the taps
+// with a non-zero alpha are folded front to back in tap order, exactly the accumulation
+// k_march_fast does one tap at a time; the decision test runs once per 64 taps.
+template <typename T, bool STATS>
+__global__ __launch_bounds__(256) void k_march_long(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
+                                                   float4 border, const LutInfo *__restrict__ info,
+                                                   uint32_t *__restrict__ out, Counters *ctr, uint32_t *touched,
+                                                   uint32_t *__restrict__ queue, const LongRay *__restrict__ long_queue)
+{
+    __shared__ float4 s_lut[kLutLds];
+    stage_lut(s_lut, lut, border);
+    const Decider dec(info);
+    const int lane = threadIdx.x & 63;
+    const uint32_t waves = gridDim.x * 4u;
+    const uint32_t entries = ctr->long_count;
+    for (uint32_t entry = blockIdx.x * 4u + (threadIdx.x >> 6); entry < entries; entry += waves) {
+        const LongRay e = long_queue[entry];
+        int px, py;
+        pixel_of_index(fp, e.pixel_id, px, py);
+        const Ray r = make_ray(fp, px, py);          // identical in every lane
+        const int last = fp.samples + 1;
+        const float step = (r.tmax - r.tmin) / (float)(uint32_t)last;
+        const RayModel rm = ray_model(r, vol, step);
+        double F0 = e.F0, F1 = e.F1, F2 = e.F2, Tr = e.Tr;
+        float S = e.S;
+        int t = e.t;
+        bool decided = false;
+        uint32_t rgba = 0xff000000u;
+        unsigned long long evaluated = 0;
+        while (t >= 1 && !decided) {
+            const int n = empty_span(vol, rm, t, -1.0f);   // wave-uniform
+            if (n > 0) {
+                t -= n;
+                continue;
+            }
+            const int tt = t - lane;
+            bool fetch = tt >= 1;
+            Cell c;
+            uint32_t brick = 0;
+            if (fetch) {
+                const Tap p = tap_position(r, vol, step, tt);
+                c = tap_cell(p, vol);
+                brick = brick_of(c, vol);
+                if (brick_empty(brick, vol)) fetch = false;
+            }
+            float4 tf = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (fetch) {
+                tf = sample_tf(s_lut, sample_volume<T>(c, brick, vol));
+                if (STATS) {
+                    evaluated++;
+                    atomicOr(&touched[brick >> 5], 1u << (brick & 31));
+                }
+            }
+            unsigned long long todo = __ballot(fetch && tf.w != 0.0f);
+            while (todo) {
+                const int src = __builtin_ctzll(todo);   // lowest lane = front-most tap of the chunk
+                todo &= todo - 1;
+                const double a = (double)__shfl(tf.w, src);
+                const double w = Tr * a;
+                F0 = __builtin_fma(w, (double)__shfl(tf.x, src), F0);
+                F1 = __builtin_fma(w, (double)__shfl(tf.y, src), F1);
+                F2 = __builtin_fma(w, (double)__shfl(tf.z, src), F2);
+                S += (float)Tr;
+                Tr = Tr * (1.0 - a);
+            }
+            t -= 64;
+            if (dec.ok && Tr < 0.03125) decided = dec.decide(F0, F1, F2, Tr, S, (t > 0 ? t : 0) + 1, rgba);
         }
+        if (!decided) {
+            // back-most tap: its colour enters unweighted by its alpha (VolumeRendering.comp:189-191)
+            const Tap p = tap_position(r, vol, step, 0);
+            const Cell c = tap_cell(p, vol);
+            const uint32_t brick = brick_of(c, vol);
+            const float4 tf = sample_tf(s_lut, sample_volume<T>(c, brick, vol));
+            if (STATS && lane == 0) {
+                evaluated++;
+                atomicOr(&touched[brick >> 5], 1u << (brick & 31));
+            }
+            F0 = __builtin_fma(Tr, (double)tf.x, F0);
+            F1 = __builtin_fma(Tr, (double)tf.y, F1);
+            F2 = __builtin_fma(Tr, (double)tf.z, F2);
+            decided = dec.ok && dec.decide(F0, F1, F2, 0.0, S, 0, rgba);
+        }
+        if (lane == 0) {
+            if (decided) out[e.pixel_id] = rgba;
+            else queue[atomicAdd(&ctr->replay_count, 1u)] = e.pixel_id;
+        }
+        if (STATS) atomicAdd(&ctr->samples_evaluated, evaluated);
     }
 }
 
 // Rays of the rectangle that hit the box (the reference marches samples + 2 taps on each).
 __global__ __launch_bounds__(256) void k_count_hits(FrameParams fp, unsigned long long *hits)
 {
+    __shared__ unsigned int s_hits;
+    if (threadIdx.x == 0) s_hits = 0;
+    __syncthreads();
     int px, py;
     uint32_t out_index;
     const bool hit = lane_pixel(fp, px, py, out_index) && make_ray(fp, px, py).hit;
     const unsigned long long mask = __ballot(hit);
-    if ((threadIdx.x & 63) == 0 && mask) atomicAdd(hits, (unsigned long long)__popcll(mask));
+    if ((threadIdx.x & 63) == 0 && mask) atomicAdd(&s_hits, (unsigned int)__popcll(mask));
+    __syncthreads();
+    if (threadIdx.x == 0 && s_hits) atomicAdd(hits, (unsigned long long)s_hits);
 }
 
 }  // namespace vr
