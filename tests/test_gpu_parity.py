@@ -389,3 +389,22 @@ def test_full_size_volume_all_modes_agree(vr, torch):
             assert st["rays_hit"] == 256 * 128
         assert frames[0][..., :3].any()
         assert np.array_equal(frames[0], frames[2]) and np.array_equal(frames[0], frames[1])
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_sort_first_bands_tile_the_frame(ctx, vr, oracle, mode):
+    w, h = 70, 53                                   # ragged: last band has 5 rows, last tile column 6 pixels
+    ctx.upload_volume(oracle.phantom(32, np.uint16))
+    ctx.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+    ctx.set_camera(*cf.CAMERAS["h30_v20"])
+    ctx.set_sampling(90)
+    ctx.set_mode(mode)
+    full = ctx.render(w, h)
+    for parts in (1, 2, 3, 5):
+        got = np.zeros_like(full)
+        for part in range(parts):
+            bands = ctx.render_bands(w, h, part, parts)
+            rows = vr.band_row_indices(h, part, parts)
+            assert bands.shape == (rows.size, w, 4)
+            got[rows] = bands
+        assert np.array_equal(got, full), parts

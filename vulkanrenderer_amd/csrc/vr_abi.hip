@@ -35,6 +35,8 @@ struct vr_ctx {
     uint32_t *empty[vr::kLevels] = {nullptr, nullptr, nullptr, nullptr};  // occupancy pyramid for the current table
     int lx[vr::kLevels] = {0}, ly[vr::kLevels] = {0}, lz[vr::kLevels] = {0};
     size_t brick_count = 0;
+    unsigned long long *micro = nullptr;  // per brick: bits of its 2^3-cell blocks
+    uint32_t *skip = nullptr;             // per brick: 2-bit code of the coarsest empty cube around it
     bool occupancy_dirty = true;
     int dtype = 0, nx = 0, ny = 0, nz = 0, nbx = 0, nby = 0, nbz = 0;
     float max_value = 0.0f, inv_hi = 0.0f, inv_lo = 0.0f;
@@ -94,6 +96,10 @@ void release_volume(vr_ctx *ctx)
         if (ctx->empty[l]) (void)hipFree(ctx->empty[l]);
         ctx->empty[l] = nullptr;
     }
+    if (ctx->micro) (void)hipFree(ctx->micro);
+    if (ctx->skip) (void)hipFree(ctx->skip);
+    ctx->micro = nullptr;
+    ctx->skip = nullptr;
     ctx->bricks = nullptr;
     ctx->cells = nullptr;
     ctx->touched = nullptr;
@@ -116,6 +122,8 @@ vr::VolumeView view_of(const vr_ctx *ctx)
         v.empty[l] = ctx->empty[l];
         v.lx[l] = ctx->lx[l]; v.ly[l] = ctx->ly[l]; v.lz[l] = ctx->lz[l];
     }
+    v.micro = ctx->micro;
+    v.skip = ctx->skip;
     return v;
 }
 
@@ -168,6 +176,8 @@ int ingest_device(vr_ctx *ctx, T *d_raw, int nx, int ny, int nz, float max_value
         const size_t cubes = (size_t)ctx->lx[l] * ctx->ly[l] * ctx->lz[l];
         VR_HIP(ctx, hipMalloc(&ctx->empty[l], ((cubes + 31) / 32) * sizeof(uint32_t)));
     }
+    VR_HIP(ctx, hipMalloc(&ctx->micro, ctx->brick_count * sizeof(unsigned long long)));
+    VR_HIP(ctx, hipMalloc(&ctx->skip, ((ctx->brick_count + 15) / 16) * sizeof(uint32_t)));
     ctx->occupancy_dirty = true;
     const unsigned brick_blocks = (unsigned)std::min<size_t>(ctx->brick_count, 1u << 20);
     hipLaunchKernelGGL((vr::k_build_bricks<T>), dim3(brick_blocks), dim3(256), 0, ctx->stream, (const T *)d_raw,
@@ -199,6 +209,16 @@ int refresh_occupancy(vr_ctx *ctx)
         hipLaunchKernelGGL(vr::k_classify_up, dim3((cubes + 255) / 256), dim3(256), 0, ctx->stream, ctx->empty[l - 1], ctx->lx[l - 1],
                            ctx->ly[l - 1], ctx->lz[l - 1], ctx->lx[l], ctx->ly[l], ctx->lz[l], ctx->empty[l]);
     }
+    const unsigned skip_words = (bricks + 15) / 16;
+    hipLaunchKernelGGL(vr::k_pack_skip, dim3((skip_words + 255) / 256), dim3(256), 0, ctx->stream, ctx->empty[0], ctx->empty[1],
+                       ctx->empty[2], ctx->lx[0], ctx->ly[0], ctx->lz[0], ctx->lx[1], ctx->ly[1], ctx->lx[2], ctx->ly[2], ctx->skip);
+    const unsigned micro_blocks =(unsigned)std::min<size_t>((ctx->brick_count + 3) / 4, 1u << 18);
+    if (ctx->dtype == VR_DTYPE_U8)
+        hipLaunchKernelGGL((vr::k_classify_micro<uint8_t>), dim3(micro_blocks), dim3(256), 0, ctx->stream, (const uint8_t *)ctx->bricks,
+                           ctx->empty[0], bricks, ctx->inv_hi, ctx->inv_lo, ctx->lut_info, ctx->micro);
+    else
+        hipLaunchKernelGGL((vr::k_classify_micro<uint16_t>), dim3(micro_blocks), dim3(256), 0, ctx->stream, (const uint16_t *)ctx->bricks,
+                           ctx->empty[0], bricks, ctx->inv_hi, ctx->inv_lo, ctx->lut_info, ctx->micro);
     VR_HIP(ctx, hipGetLastError());
     ctx->occupancy_dirty = false;
     return VR_OK;

@@ -39,6 +39,10 @@ struct VolumeView {
     // can receive a non-zero alpha.  Grid of level l: lx[l] x ly[l] x lz[l] cubes.
     const uint32_t *empty[4];
     int lx[4], ly[4], lz[4];
+    const uint32_t *skip;   // 2 bits per brick: 0 occupied, else 1 + coarsest empty level (0..2) around it
+    // Below the bricks: per brick one bit per 2^3-cell block (4 x 4 x 4 of them, bit z*16 + y*4 + x),
+    // set when every tap whose low corner lies in the block gets alpha exactly 0.
+    const unsigned long long *micro;
 };
 constexpr int kLevels = 4;
 

@@ -151,6 +151,51 @@ __global__ __launch_bounds__(256) void k_classify_up(const uint32_t *__restrict_
     store_ballot(empty, blockIdx.x * 256u + (threadIdx.x & ~63u), count, parent);
 }
 
+// Below level 0: one 64-bit word per brick, one bit per block of 2^3 cells.  A tap whose low
+// corner lies in block (bx, by, bz) of the brick filters the voxels [2b, 2b+2]^3 (local, apron
+// included); the block is empty when the transfer function is exactly transparent over their range.
+// One wave per brick, one lane per block.  Empty bricks get all ones without touching their voxels.
+template <typename T>
+__global__ __launch_bounds__(256) void k_classify_micro(const T *__restrict__ bricks, const uint32_t *__restrict__ empty0,
+                                                       uint32_t brick_count, float inv_hi, float inv_lo,
+                                                       const LutInfo *__restrict__ info,
+                                                       unsigned long long *__restrict__ micro)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t waves = gridDim.x * 4u;
+    const int bx = (lane & 3) * 2, by = ((lane >> 2) & 3) * 2, bz = (lane >> 4) * 2;
+    for (uint32_t brick = blockIdx.x * 4u + (threadIdx.x >> 6); brick < brick_count; brick += waves) {
+        if ((empty0[brick >> 5] >> (brick & 31)) & 1u) {
+            if (lane == 0) micro[brick] = ~0ull;
+            continue;
+        }
+        const T *src = bricks + (size_t)brick * kBrickElems + (bz * kRow + by) * kRow + bx;
+        uint32_t mn = 0xffffffffu, mx = 0;
+#pragma unroll
+        for (int z = 0; z < 3; z++)
+#pragma unroll
+            for (int y = 0; y < 3; y++)
+#pragma unroll
+                for (int x = 0; x < 3; x++) {
+                    const uint32_t v = src[(z * kRow + y) * kRow + x];
+                    mn = v < mn ? v : mn;
+                    mx = v > mx ? v : mx;
+                }
+        const float lo = (float)mn, hi = (float)mx;
+        int first, last;
+        tf_entry_range(__builtin_fmaf(lo, inv_hi, lo * inv_lo), __builtin_fmaf(hi, inv_hi, hi * inv_lo), first, last);
+        const bool empty = info->bad_prefix[last + 1] == info->bad_prefix[first];
+        const unsigned long long mask = __ballot(empty);
+        if (lane == 0) micro[brick] = mask;
+    }
+}
+
+__device__ __forceinline__ bool micro_empty(unsigned long long mask, const Cell &c)
+{
+    const int bit = (((c.sz & 7) >> 1) << 4) | (((c.sy & 7) >> 1) << 2) | ((c.sx & 7) >> 1);
+    return (mask >> bit) & 1ull;
+}
+
 // ---- stepping over empty space ----------------------------------------------------------------
 // Along a ray the padded texel coordinate G = u*size - 0.5 + kPad is, in real arithmetic, linear
 // in the tap index t: G(t) = a + t*b.  The marches walk this line model to find empty regions and
@@ -202,26 +247,45 @@ __device__ __forceinline__ int span_inside(float gx, float gy, float gz, int lox
     return 1 + (int)fminf(n, 1e9f);
 }
 
-// Coarsest empty pyramid level that contains brick (cx, cy, cz), or -1.  The four words are
-// independent loads, so they are in flight together.
+// The pyramid folded into one table the marches read: two bits per brick, 0 = occupied, otherwise
+// 1 + the coarsest of the levels 0..2 whose cube around the brick is empty.  One load answers
+// "how far can I step from here".
+__global__ __launch_bounds__(256) void k_pack_skip(const uint32_t *__restrict__ e0, const uint32_t *__restrict__ e1,
+                                                  const uint32_t *__restrict__ e2, int nx0, int ny0, int nz0, int nx1, int ny1,
+                                                  int nx2, int ny2, uint32_t *__restrict__ skip)
+{
+    const uint32_t word = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t bricks = (uint32_t)(nx0 * ny0 * nz0);
+    if (word * 16u >= bricks) return;
+    uint32_t packed = 0;
+    for (uint32_t k = 0; k < 16u; k++) {
+        const uint32_t b = word * 16u + k;
+        if (b >= bricks) break;
+        const int x = b % nx0, y = (b / nx0) % ny0, z = b / (nx0 * ny0);
+        const uint32_t i1 = (uint32_t)(((z >> 2) * ny1 + (y >> 2)) * nx1 + (x >> 2));
+        const uint32_t i2 = (uint32_t)(((z >> 4) * ny2 + (y >> 4)) * nx2 + (x >> 4));
+        uint32_t code = (e0[b >> 5] >> (b & 31)) & 1u;
+        if ((e1[i1 >> 5] >> (i1 & 31)) & 1u) code = 2;
+        if ((e2[i2 >> 5] >> (i2 & 31)) & 1u) code = 3;
+        packed |= code << (2 * k);
+    }
+    skip[word] = packed;
+}
+
+__device__ __forceinline__ uint32_t skip_code(uint32_t brick, const VolumeView &v)
+{
+    return (v.skip[brick >> 4] >> ((brick & 15u) * 2u)) & 3u;
+}
+
+// Coarsest empty pyramid level (0..2) that contains brick (cx, cy, cz), or -1.
 __device__ __forceinline__ int empty_level(const VolumeView &v, int cx, int cy, int cz)
 {
-    uint32_t bit[kLevels];
-#pragma unroll
-    for (int l = 0; l < kLevels; l++) {
-        const uint32_t i = (uint32_t)((((cz >> (2 * l)) * v.ly[l]) + (cy >> (2 * l))) * v.lx[l] + (cx >> (2 * l)));
-        bit[l] = (v.empty[l][i >> 5] >> (i & 31)) & 1u;
-    }
-    int level = -1;
-#pragma unroll
-    for (int l = 0; l < kLevels; l++)
-        if (bit[l]) level = l;
-    return level;
+    return (int)skip_code((uint32_t)((cz * v.ly[0] + cy) * v.lx[0] + cx), v) - 1;
 }
 
 __device__ __forceinline__ bool brick_empty(uint32_t brick, const VolumeView &v)
 {
-    return (v.empty[0][brick >> 5] >> (brick & 31)) & 1u;
+    return skip_code(brick, v) != 0u;
 }
 
 // How many taps, starting at t and walking in direction dir, can be stepped over because the line
@@ -253,6 +317,14 @@ __device__ __forceinline__ int empty_span_at(const VolumeView &v, const RayModel
     const int shift = 3 + 2 * level;
     return span_inside(gx, gy, gz, (cx >> (2 * level)) << shift, (cy >> (2 * level)) << shift, (cz >> (2 * level)) << shift,
                        (float)(1 << shift), m, dir);
+}
+
+// Taps t, t + dir, ... whose model position stays inside the 2^3-cell block that holds cell c.
+__device__ __forceinline__ int block_span(const RayModel &m, int t, float dir, const Cell &c)
+{
+    const float ft = (float)t;
+    const float gx = __builtin_fmaf(ft, m.bx, m.ax), gy = __builtin_fmaf(ft, m.by, m.ay), gz = __builtin_fmaf(ft, m.bz, m.az);
+    return span_inside(gx, gy, gz, c.sx & ~1, c.sy & ~1, c.sz & ~1, 2.0f, m, dir);
 }
 
 // ---- reference-order march ---------------------------------------------------------------------
@@ -291,7 +363,7 @@ __global__ __launch_bounds__(256) void k_march_exact(VolumeView vol, FrameParams
             const Tap p = tap_position(r, vol, step, t);
             const Cell c = tap_cell(p, vol);
             const uint32_t brick = brick_of(c, vol);
-            if (SKIP && t > 0 && brick_empty(brick, vol)) {
+            if (SKIP && t > 0 && (brick_empty(brick, vol) || micro_empty(vol.micro[brick], c))) {
                 t++;
                 continue;
             }
@@ -363,7 +435,7 @@ __global__ __launch_bounds__(256) void k_replay_exact(VolumeView vol, FrameParam
                 const Tap p = tap_position(r, vol, step, t);
                 c = tap_cell(p, vol);
                 brick = brick_of(c, vol);
-                if (t > 0 && brick_empty(brick, vol)) fetch = false;
+                if (t > 0 && (brick_empty(brick, vol) || micro_empty(vol.micro[brick], c))) fetch = false;
             }
             float4 tf = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (fetch) {
@@ -502,7 +574,9 @@ __global__ __launch_bounds__(256) void k_march_fast(VolumeView vol, FrameParams 
 
     auto try_decide = [&](int taps_left) -> bool { return dec.decide(F0, F1, F2, Tr, S, taps_left, rgba); };
 
-    uint32_t solid = 0xffffffffu;       // last brick found occupied: its taps need no occupancy lookup
+    uint32_t solid = 0xffffffffu;       // last brick found occupied: its taps need no pyramid lookup
+    unsigned long long solid_mask = 0;  // and its 2^3-cell block bits
+    bool in_air = true;                 // the last tap looked at was in an empty cube
     for (int round = 0; round < kLaneBudget; round++) {
         // 1. step over empty space until this lane stands on a tap that must be fetched
         bool have = false;
@@ -510,21 +584,40 @@ __global__ __launch_bounds__(256) void k_march_fast(VolumeView vol, FrameParams 
         uint32_t brick = 0;
         while (marching && !have) {
             if (t < 1) { marching = false; break; }
+            if (in_air) {
+                // crossing empty space: walk the line model, no exact positions needed
+                if (STATS) lookups++;
+                const int n = empty_span(vol, rm, t, -1.0f);
+                if (n > 0) {
+                    t -= n;
+                    continue;
+                }
+            }
             const Tap p = tap_position(r, vol, step, t);
             c = tap_cell(p, vol);
             brick = brick_of(c, vol);
-            if (brick == solid) { have = true; break; }
-            if (STATS) lookups++;
-            const int level = empty_level(vol, c.sx >> 3, c.sy >> 3, c.sz >> 3);
-            if (level < 0) {
+            if (brick != solid) {
+                if (STATS) lookups++;
+                const int level = empty_level(vol, c.sx >> 3, c.sy >> 3, c.sz >> 3);
+                if (level >= 0) {
+                    // tap t is in an empty cube for certain (exact cell); the line model says how
+                    // many of the following taps are too
+                    const int n = empty_span_at(vol, rm, t, -1.0f, level, c.sx >> 3, c.sy >> 3, c.sz >> 3);
+                    t -= n > 1 ? n : 1;
+                    in_air = true;
+                    continue;
+                }
                 solid = brick;
-                have = true;
-                break;
+                solid_mask = vol.micro[brick];
             }
-            // tap t is in an empty cube for certain (exact cell); the line model says how many of
-            // the following taps are too
-            const int n = empty_span_at(vol, rm, t, -1.0f, level, c.sx >> 3, c.sy >> 3, c.sz >> 3);
-            t -= n > 1 ? n : 1;
+            in_air = false;
+            if (micro_empty(solid_mask, c)) {
+                // occupied brick, transparent 2^3-cell block of it: step to the block's far side
+                const int n = block_span(rm, t, -1.0f, c);
+                t -= n > 1 ? n : 1;
+            } else {
+                have = true;
+            }
         }
         // 2. the wave leaves the loop when no lane has a tap to fetch
         if (__ballot(have) == 0ull) break;
@@ -644,7 +737,7 @@ __global__ __launch_bounds__(256) void k_march_long(VolumeView vol, FrameParams 
                 const Tap p = tap_position(r, vol, step, tt);
                 c = tap_cell(p, vol);
                 brick = brick_of(c, vol);
-                if (brick_empty(brick, vol)) fetch = false;
+                if (brick_empty(brick, vol) || micro_empty(vol.micro[brick], c)) fetch = false;
             }
             float4 tf = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (fetch) {
