@@ -54,6 +54,19 @@ for a, b in zip(edges[:-1], edges[1:]):
     resident = int(np.count_nonzero((t0 <= mid) & (t1 > mid)))
     started = int(np.count_nonzero((t0 >= a) & (t0 < b)))
     print("t=%7.0f us resident %6d (%.2f per SIMD) started %6d" % (mid, resident, resident / 1024.0, started))
+info = t[:, 3].astype(np.uint64)
+rounds = (info & np.uint64(0xfff)).astype(np.float64)
+mmodel = ((info >> np.uint64(12)) & np.uint64(0xfff)).astype(np.float64)
+mexact = ((info >> np.uint64(24)) & np.uint64(0xfff)).astype(np.float64)
+mboth = ((info >> np.uint64(36)) & np.uint64(0xfff)).astype(np.float64)
+ssum = ((info >> np.uint64(48)) & np.uint64(0xffff)).astype(np.float64)
+print("per wave: rounds mean %.1f p90 %.0f max %.0f | max-lane model iters mean %.1f | exact iters mean %.1f | both mean %.1f p90 %.0f | "
+      "sampled lane-rounds mean %.0f -> lane use in sample rounds %.2f" % (
+          rounds.mean(), np.percentile(rounds, 90), rounds.max(), mmodel.mean(), mexact.mean(), mboth.mean(),
+          np.percentile(mboth, 90), ssum.mean(), ssum.sum() / max(1.0, (rounds * 64).sum())))
+busy = rounds > 0
+print("waves with rounds:", int(busy.sum()), "their dur mean %.1f us, rounds mean %.1f, both mean %.1f" % (dur[busy].mean(), rounds[busy].mean(), mboth[busy].mean()))
+print("waves without rounds: dur mean %.1f us, both mean %.1f" % (dur[~busy].mean(), mboth[~busy].mean()))
 hw = t[:, 2]
 xcc = hw >> 32
 print("waves per XCC", np.bincount(xcc.astype(np.int64), minlength=8))

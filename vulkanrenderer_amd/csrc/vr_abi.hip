@@ -36,6 +36,7 @@ struct vr_ctx {
     int lx[vr::kLevels] = {0}, ly[vr::kLevels] = {0}, lz[vr::kLevels] = {0};
     size_t brick_count = 0;
     unsigned long long *micro = nullptr;  // per brick: bits of its 2^3-cell blocks
+    int *occ = nullptr;                   // bounding box of the occupied bricks (6 ints)
     uint32_t *skip = nullptr;             // per brick: 2-bit code of the coarsest empty cube around it
     bool occupancy_dirty = true;
     int dtype = 0, nx = 0, ny = 0, nz = 0, nbx = 0, nby = 0, nbz = 0;
@@ -124,6 +125,7 @@ vr::VolumeView view_of(const vr_ctx *ctx)
     }
     v.micro = ctx->micro;
     v.skip = ctx->skip;
+    v.occ = ctx->occ;
     return v;
 }
 
@@ -209,6 +211,11 @@ int refresh_occupancy(vr_ctx *ctx)
         hipLaunchKernelGGL(vr::k_classify_up, dim3((cubes + 255) / 256), dim3(256), 0, ctx->stream, ctx->empty[l - 1], ctx->lx[l - 1],
                            ctx->ly[l - 1], ctx->lz[l - 1], ctx->lx[l], ctx->ly[l], ctx->lz[l], ctx->empty[l]);
     }
+    const int occ_init[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, -1, -1, -1};
+    VR_HIP(ctx, hipMemcpyAsync(ctx->occ, occ_init, sizeof occ_init, hipMemcpyHostToDevice, ctx->stream));
+    VR_HIP(ctx, hipStreamSynchronize(ctx->stream));  // occ_init lives on this stack frame
+    hipLaunchKernelGGL(vr::k_occupied_bounds, dim3(1024), dim3(256), 0, ctx->stream, ctx->empty[0], ctx->lx[0], ctx->ly[0], ctx->lz[0],
+                       ctx->occ);
     const unsigned skip_words = (bricks + 15) / 16;
     hipLaunchKernelGGL(vr::k_pack_skip, dim3((skip_words + 255) / 256), dim3(256), 0, ctx->stream, ctx->empty[0], ctx->empty[1],
                        ctx->empty[2], ctx->lx[0], ctx->ly[0], ctx->lz[0], ctx->lx[1], ctx->ly[1], ctx->lx[2], ctx->ly[2], ctx->skip);
@@ -300,6 +307,7 @@ int vr_create(int device, vr_ctx **out)
         hipMalloc(&ctx->lut, 1024 * sizeof(float)) != hipSuccess ||
         hipMalloc(&ctx->counters, sizeof(vr::Counters)) != hipSuccess ||
         hipMalloc(&ctx->lut_info, sizeof(vr::LutInfo)) != hipSuccess ||
+        hipMalloc(&ctx->occ, 6 * sizeof(int)) != hipSuccess ||
         hipMemset(ctx->lut, 0, 1024 * sizeof(float)) != hipSuccess ||  // main.cpp:110: zero-initialised table
         hipMemset(ctx->counters, 0, sizeof(vr::Counters)) != hipSuccess ||
         hipMemcpyToSymbol(HIP_SYMBOL(vr::d_phantom), vr::PHANTOM, sizeof(vr::PHANTOM)) != hipSuccess) {
@@ -331,6 +339,7 @@ int vr_destroy(vr_ctx *ctx)
     if (ctx->queue) (void)hipFree(ctx->queue);
     if (ctx->long_queue) (void)hipFree(ctx->long_queue);
     if (ctx->lut_info) (void)hipFree(ctx->lut_info);
+    if (ctx->occ) (void)hipFree(ctx->occ);
     for (hipEvent_t e : ctx->ring_a)
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->ring_b)

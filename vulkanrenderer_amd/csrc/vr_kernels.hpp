@@ -39,6 +39,7 @@ struct VolumeView {
     // can receive a non-zero alpha.  Grid of level l: lx[l] x ly[l] x lz[l] cubes.
     const uint32_t *empty[4];
     int lx[4], ly[4], lz[4];
+    const int *occ;         // bounding box of the occupied bricks: lo x,y,z then hi x,y,z (brick coordinates)
     const uint32_t *skip;   // 2 bits per brick: 0 occupied, else 1 + coarsest empty level (0..2) around it
     // Below the bricks: per brick one bit per 2^3-cell block (4 x 4 x 4 of them, bit z*16 + y*4 + x),
     // set when every tap whose low corner lies in the block gets alpha exactly 0.
@@ -222,9 +223,9 @@ __device__ __forceinline__ float4 sample_tf(const float4 *s_lut, float intensity
 
 __device__ __forceinline__ uint32_t to_unorm8(float x)
 {
-    if (!(x > 0.0f)) return 0u;
-    if (x >= 1.0f) return 255u;
-    return (uint32_t)__float2int_rn(x * 255.0f);
+    // NaN and negatives to 0, >= 1 to 255, else round-half-even of x * 255; written without branches
+    // (fmaxf returns the other operand for a NaN)
+    return (uint32_t)__float2int_rn(fminf(fmaxf(x, 0.0f), 1.0f) * 255.0f);
 }
 
 __device__ __forceinline__ uint32_t pack_rgba8(float r, float g, float b)

@@ -11,6 +11,10 @@
 
 namespace vr {
 
+#ifndef VR_FAST_MIN_WAVES
+#define VR_FAST_MIN_WAVES 1
+#endif
+
 #ifdef VR_DIAG
 __device__ unsigned long long *g_vr_timeline = nullptr;
 #endif
@@ -205,12 +209,19 @@ __device__ __forceinline__ bool micro_empty(unsigned long long mask, const Cell 
 // texels on each side: a tap whose model position is inside the shrunk region has its true low
 // corner inside the region.
 struct RayModel {
-    float ax, ay, az;
+    float ax, ay, az;   // G(t) = a + t * b
     float bx, by, bz;
+    // for counting taps while walking in the march direction (tap index changing by `dir` per step):
+    float ix, iy, iz;   // 1 / (dir * b), 0 where the ray does not move along the axis
+    float ux, uy, uz;   // 1 where the walk increases the coordinate (leaves through the upper face)
+    float sx, sy, sz;   // 1e9 where the ray does not move along the axis (never leaves), else 0
     float margin;
+    // Taps outside [t_stop, t_first] lie outside the bounding box of all occupied bricks (widened
+    // by a voxel and a tap): they are in empty bricks and need no look at all.
+    int t_first, t_stop;
 };
 
-__device__ __forceinline__ RayModel ray_model(const Ray &r, const VolumeView &v, float step)
+__device__ __forceinline__ RayModel ray_model(const Ray &r, const VolumeView &v, float step, float dir)
 {
     RayModel m;
     // world(t) = o + (tmax - t*step)*d; u = x + .5, v = y + .5, w = -z inside the box
@@ -221,30 +232,92 @@ __device__ __forceinline__ RayModel ray_model(const Ray &r, const VolumeView &v,
     m.bx = -(step * r.d[0]) * v.fx;
     m.by = -(step * r.d[1]) * v.fy;
     m.bz = (step * r.d[2]) * v.fz;
+    // the reciprocals only serve the tap counts of the line model, which the margin protects
+    const float dx = dir * m.bx, dy = dir * m.by, dz = dir * m.bz;
+    m.ix = dx != 0.0f ? __builtin_amdgcn_rcpf(dx) : 0.0f;
+    m.iy = dy != 0.0f ? __builtin_amdgcn_rcpf(dy) : 0.0f;
+    m.iz = dz != 0.0f ? __builtin_amdgcn_rcpf(dz) : 0.0f;
+    m.ux = dx > 0.0f ? 1.0f : 0.0f;
+    m.uy = dy > 0.0f ? 1.0f : 0.0f;
+    m.uz = dz > 0.0f ? 1.0f : 0.0f;
+    m.sx = dx != 0.0f ? 0.0f : 1e9f;
+    m.sy = dy != 0.0f ? 0.0f : 1e9f;
+    m.sz = dz != 0.0f ? 0.0f : 1e9f;
     const float big = fmaxf(v.fx, fmaxf(v.fy, v.fz));
     m.margin = fmaxf(0.02f, big * 1e-5f);
+    // clip the tap range against the box of occupied bricks: G(t) = a + t*b inside [L, U] per axis
+    float t_lo = 0.0f, t_hi = 3e9f;
+    const float a[3] = {m.ax, m.ay, m.az}, b[3] = {m.bx, m.by, m.bz}, inv[3] = {dir * m.ix, dir * m.iy, dir * m.iz};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float L = (float)(v.occ[k] * kBrick) - 1.0f - m.margin, U = (float)((v.occ[3 + k] + 1) * kBrick) + 1.0f + m.margin;
+        if (b[k] != 0.0f) {
+            const float t1 = (L - a[k]) * inv[k], t2 = (U - a[k]) * inv[k];
+            t_lo = fmaxf(t_lo, fminf(t1, t2));
+            t_hi = fminf(t_hi, fmaxf(t1, t2));
+        } else if (!(a[k] >= L && a[k] <= U)) {
+            t_hi = -1.0f;
+        }
+    }
+    // one tap of slack on each side for the rounding of the model
+    m.t_first = t_hi >= t_lo ? (int)fminf(t_hi + 2.0f, 2e9f) : 0;
+    m.t_stop = t_hi >= t_lo ? (int)fmaxf(t_lo - 1.0f, 1.0f) : 0x7fffffff;
+    if (m.t_stop < 1) m.t_stop = 1;
     return m;
 }
 
-// Taps t, t + dir, t + 2*dir, ... (dir = +1 or -1) whose model position stays inside the cube
-// [lo, lo + extent)^3 shrunk by the margin; 0 when tap t itself is not inside.
-__device__ __forceinline__ float axis_span(float g, float lo, float extent, float d, float margin)
+// Bounding box (brick coordinates, inclusive) of the occupied bricks; lo > hi when there is none.
+__global__ __launch_bounds__(256) void k_occupied_bounds(const uint32_t *__restrict__ empty0, int nx, int ny, int nz, int *occ)
 {
-    const float a = lo + margin, b = lo + extent - margin;
-    if (!(g >= a && g <= b)) return -1.0f;
-    if (d > 0.0f) return (b - g) / d;
-    if (d < 0.0f) return (a - g) / d;
-    return 1e9f;
+    __shared__ int s_lo[3][4], s_hi[3][4];
+    const uint32_t bricks = (uint32_t)(nx * ny * nz);
+    int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
+    for (uint32_t b = blockIdx.x * 256u + threadIdx.x; b < bricks; b += gridDim.x * 256u) {
+        if ((empty0[b >> 5] >> (b & 31)) & 1u) continue;
+        const int c[3] = {(int)(b % (uint32_t)nx), (int)((b / (uint32_t)nx) % (uint32_t)ny), (int)(b / (uint32_t)(nx * ny))};
+        for (int k = 0; k < 3; k++) {
+            lo[k] = min(lo[k], c[k]);
+            hi[k] = max(hi[k], c[k]);
+        }
+    }
+    for (int k = 0; k < 3; k++) {
+        for (int o = 32; o > 0; o >>= 1) {
+            lo[k] = min(lo[k], __shfl_xor(lo[k], o));
+            hi[k] = max(hi[k], __shfl_xor(hi[k], o));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            s_lo[k][threadIdx.x >> 6] = lo[k];
+            s_hi[k][threadIdx.x >> 6] = hi[k];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int k = threadIdx.x;
+        atomicMin(&occ[k], min(min(s_lo[k][0], s_lo[k][1]), min(s_lo[k][2], s_lo[k][3])));
+        atomicMax(&occ[3 + k], max(max(s_hi[k][0], s_hi[k][1]), max(s_hi[k][2], s_hi[k][3])));
+    }
 }
 
-__device__ __forceinline__ int span_inside(float gx, float gy, float gz, int lox, int loy, int loz, float extent,
-                                           const RayModel &m, float dir)
+// Steps (possibly fractional) until the model position leaves [lo, lo + extent) shrunk by the
+// margin along one axis; negative when it is not inside now.  Branch-free on purpose.
+__device__ __forceinline__ float axis_span(float g, float lo, float extent, float inv, float up, float still, float margin)
 {
-    float n = axis_span(gx, (float)lox, extent, dir * m.bx, m.margin);
-    n = fminf(n, axis_span(gy, (float)loy, extent, dir * m.by, m.margin));
-    n = fminf(n, axis_span(gz, (float)loz, extent, dir * m.bz, m.margin));
-    if (!(n >= 0.0f)) return 0;
-    return 1 + (int)fminf(n, 1e9f);
+    const float a = lo + margin, b = lo + extent - margin;
+    const float target = up != 0.0f ? b : a;
+    const float n = (target - g) * inv * 0.9999f + still;   // the reciprocal is good to 1 ulp: round the count down
+    return (g >= a && g <= b) ? n : -1.0f;
+}
+
+// Taps t, t + dir, t + 2*dir, ... whose model position stays inside the cube [lo, lo + extent)^3
+// shrunk by the margin; 0 when tap t itself is not inside.
+__device__ __forceinline__ int span_inside(float gx, float gy, float gz, int lox, int loy, int loz, float extent,
+                                           const RayModel &m)
+{
+    float n = axis_span(gx, (float)lox, extent, m.ix, m.ux, m.sx, m.margin);
+    n = fminf(n, axis_span(gy, (float)loy, extent, m.iy, m.uy, m.sy, m.margin));
+    n = fminf(n, axis_span(gz, (float)loz, extent, m.iz, m.uz, m.sz, m.margin));
+    n = fminf(n, 1e9f);
+    return n >= 0.0f ? 1 + (int)n : 0;
 }
 
 // The pyramid folded into one table the marches read: two bits per brick, 0 = occupied, otherwise
@@ -290,7 +363,7 @@ __device__ __forceinline__ bool brick_empty(uint32_t brick, const VolumeView &v)
 
 // How many taps, starting at t and walking in direction dir, can be stepped over because the line
 // model puts them inside an empty cube of the pyramid.  0: tap t needs an exact look.
-__device__ __forceinline__ int empty_span(const VolumeView &v, const RayModel &m, int t, float dir)
+__device__ __forceinline__ int empty_span(const VolumeView &v, const RayModel &m, int t)
 {
     const float ft = (float)t;
     const float gx = __builtin_fmaf(ft, m.bx, m.ax), gy = __builtin_fmaf(ft, m.by, m.ay), gz = __builtin_fmaf(ft, m.bz, m.az);
@@ -304,27 +377,27 @@ __device__ __forceinline__ int empty_span(const VolumeView &v, const RayModel &m
     if (level < 0) return 0;
     const int shift = 3 + 2 * level;
     return span_inside(gx, gy, gz, (cx >> (2 * level)) << shift, (cy >> (2 * level)) << shift, (cz >> (2 * level)) << shift,
-                       (float)(1 << shift), m, dir);
+                       (float)(1 << shift), m);
 }
 
 // The same count when the tap's exact brick (cx, cy, cz) is already known to lie in an empty cube of
 // pyramid level `level`: taps t, t + dir, ... whose model position stays inside that cube.
-__device__ __forceinline__ int empty_span_at(const VolumeView &v, const RayModel &m, int t, float dir, int level, int cx,
+__device__ __forceinline__ int empty_span_at(const VolumeView &v, const RayModel &m, int t, int level, int cx,
                                              int cy, int cz)
 {
     const float ft = (float)t;
     const float gx = __builtin_fmaf(ft, m.bx, m.ax), gy = __builtin_fmaf(ft, m.by, m.ay), gz = __builtin_fmaf(ft, m.bz, m.az);
     const int shift = 3 + 2 * level;
     return span_inside(gx, gy, gz, (cx >> (2 * level)) << shift, (cy >> (2 * level)) << shift, (cz >> (2 * level)) << shift,
-                       (float)(1 << shift), m, dir);
+                       (float)(1 << shift), m);
 }
 
 // Taps t, t + dir, ... whose model position stays inside the 2^3-cell block that holds cell c.
-__device__ __forceinline__ int block_span(const RayModel &m, int t, float dir, const Cell &c)
+__device__ __forceinline__ int block_span(const RayModel &m, int t, const Cell &c)
 {
     const float ft = (float)t;
     const float gx = __builtin_fmaf(ft, m.bx, m.ax), gy = __builtin_fmaf(ft, m.by, m.ay), gz = __builtin_fmaf(ft, m.bz, m.az);
-    return span_inside(gx, gy, gz, c.sx & ~1, c.sy & ~1, c.sz & ~1, 2.0f, m, dir);
+    return span_inside(gx, gy, gz, c.sx & ~1, c.sy & ~1, c.sz & ~1, 2.0f, m);
 }
 
 // ---- reference-order march ---------------------------------------------------------------------
@@ -349,12 +422,14 @@ __global__ __launch_bounds__(256) void k_march_exact(VolumeView vol, FrameParams
     if (r.hit) {
         const int last = fp.samples + 1;
         const float step = (r.tmax - r.tmin) / (float)(uint32_t)last;
-        const RayModel rm = ray_model(r, vol, step);
+        const RayModel rm = ray_model(r, vol, step, 1.0f);
         int t = 0;
         while (t <= last) {
             if (SKIP && t > 0) {
+                if (t < rm.t_stop) t = rm.t_stop;      // nothing occupied before or beyond these taps
+                if (t > rm.t_first || t > last) break;
                 if (STATS) lookups++;
-                const int n = empty_span(vol, rm, t, 1.0f);
+                const int n = empty_span(vol, rm, t);
                 if (n > 0) {
                     t += n;
                     continue;
@@ -415,13 +490,15 @@ __global__ __launch_bounds__(256) void k_replay_exact(VolumeView vol, FrameParam
         const Ray r = make_ray(fp, px, py);          // identical in every lane
         const int last = fp.samples + 1;
         const float step = (r.tmax - r.tmin) / (float)(uint32_t)last;
-        const RayModel rm = ray_model(r, vol, step);
+        const RayModel rm = ray_model(r, vol, step, 1.0f);
         float cr = 0.0f, cg = 0.0f, cb = 0.0f;
         unsigned long long evaluated = 0;
         int base = 0;
         while (base <= last) {
             if (base > 0) {
-                const int n = empty_span(vol, rm, base, 1.0f);   // wave-uniform: whole runs of empty taps
+                if (base < rm.t_stop) base = rm.t_stop;    // nothing occupied before or beyond these taps
+                if (base > rm.t_first || base > last) break;
+                const int n = empty_span(vol, rm, base);   // wave-uniform: whole runs of empty taps
                 if (n > 0) {
                     base += n;
                     continue;
@@ -522,7 +599,10 @@ struct LongRay {
 // Fetch rounds a lane spends on its ray before it hands the rest over: bounds the serial,
 // latency-bound chain a single slow ray (one that grazes the object without ever becoming opaque)
 // can keep its wave alive for.
-constexpr int kLaneBudget = 64;
+#ifndef VR_LANE_BUDGET
+#define VR_LANE_BUDGET 64
+#endif
+constexpr int kLaneBudget = VR_LANE_BUDGET;
 
 // ---- front-to-back march ------------------------------------------------------------------------
 // Visits the taps from the eye towards the back, steps over empty cubes of the occupancy pyramid,
@@ -542,7 +622,7 @@ constexpr int kLaneBudget = 64;
 // The loop leaves a wave when no lane has a tap left (wavefront ballot): lanes first step over
 // empty space (cheap, divergent), then all lanes that found a tap fetch it together.
 template <typename T, bool STATS>
-__global__ __launch_bounds__(256) void k_march_fast(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
+__global__ __launch_bounds__(256, VR_FAST_MIN_WAVES) void k_march_fast(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
                                                    float4 border, const LutInfo *__restrict__ info,
                                                    uint32_t *__restrict__ out, Counters *ctr, uint32_t *touched,
                                                    uint32_t *__restrict__ queue, LongRay *__restrict__ long_queue)
@@ -550,6 +630,7 @@ __global__ __launch_bounds__(256) void k_march_fast(VolumeView vol, FrameParams 
     __shared__ float4 s_lut[kLutLds];
 #ifdef VR_DIAG
     const unsigned long long diag_t0 = wall_clock64();
+    unsigned int diag_model = 0, diag_exact = 0, diag_rounds = 0, diag_sampled = 0;
 #endif
     stage_lut(s_lut, lut, border);
     int px, py;
@@ -562,11 +643,12 @@ __global__ __launch_bounds__(256) void k_march_fast(VolumeView vol, FrameParams 
 
     const int last = fp.samples + 1;
     const float step = (r.tmax - r.tmin) / (float)(uint32_t)last;
-    const RayModel rm = ray_model(r, vol, step);
+    const RayModel rm = ray_model(r, vol, step, -1.0f);
 
     double F0 = 0.0, F1 = 0.0, F2 = 0.0, Tr = 1.0;
     float S = 0.0f;
-    int t = last;                       // front-most tap
+    int t = last < rm.t_first ? last : rm.t_first;   // front-most tap that can matter
+    const int t_stop = rm.t_stop;       // taps below it (the back tap aside) cannot matter either
     bool marching = in_rect && r.hit;   // still has taps with index >= 1 to visit
     bool decided = false;
     uint32_t rgba = 0xff000000u;        // miss: clear colour (VolumeRendering.comp:174,180)
@@ -583,16 +665,22 @@ __global__ __launch_bounds__(256) void k_march_fast(VolumeView vol, FrameParams 
         Cell c;
         uint32_t brick = 0;
         while (marching && !have) {
-            if (t < 1) { marching = false; break; }
+            if (t < t_stop) { marching = false; break; }
             if (in_air) {
                 // crossing empty space: walk the line model, no exact positions needed
+#ifdef VR_DIAG
+                diag_model++;
+#endif
                 if (STATS) lookups++;
-                const int n = empty_span(vol, rm, t, -1.0f);
+                const int n = empty_span(vol, rm, t);
                 if (n > 0) {
                     t -= n;
                     continue;
                 }
             }
+#ifdef VR_DIAG
+            diag_exact++;
+#endif
             const Tap p = tap_position(r, vol, step, t);
             c = tap_cell(p, vol);
             brick = brick_of(c, vol);
@@ -602,7 +690,7 @@ __global__ __launch_bounds__(256) void k_march_fast(VolumeView vol, FrameParams 
                 if (level >= 0) {
                     // tap t is in an empty cube for certain (exact cell); the line model says how
                     // many of the following taps are too
-                    const int n = empty_span_at(vol, rm, t, -1.0f, level, c.sx >> 3, c.sy >> 3, c.sz >> 3);
+                    const int n = empty_span_at(vol, rm, t, level, c.sx >> 3, c.sy >> 3, c.sz >> 3);
                     t -= n > 1 ? n : 1;
                     in_air = true;
                     continue;
@@ -613,7 +701,7 @@ __global__ __launch_bounds__(256) void k_march_fast(VolumeView vol, FrameParams 
             in_air = false;
             if (micro_empty(solid_mask, c)) {
                 // occupied brick, transparent 2^3-cell block of it: step to the block's far side
-                const int n = block_span(rm, t, -1.0f, c);
+                const int n = block_span(rm, t, c);
                 t -= n > 1 ? n : 1;
             } else {
                 have = true;
@@ -621,6 +709,10 @@ __global__ __launch_bounds__(256) void k_march_fast(VolumeView vol, FrameParams 
         }
         // 2. the wave leaves the loop when no lane has a tap to fetch
         if (__ballot(have) == 0ull) break;
+#ifdef VR_DIAG
+        diag_rounds++;
+        diag_sampled += have ? 1u : 0u;
+#endif
         if (have) {
             const float inten = sample_volume<T>(c, brick, vol);
             const float4 tf = sample_tf(s_lut, inten);
@@ -679,6 +771,13 @@ __global__ __launch_bounds__(256) void k_march_fast(VolumeView vol, FrameParams 
     }
 #ifdef VR_DIAG
     // diagnostic build only: wave start/end wall clock (100 MHz) and placement, one record per wave
+    unsigned int diag_both = diag_model + diag_exact, diag_sum = diag_sampled;
+    for (int o = 32; o > 0; o >>= 1) {
+        diag_model = max(diag_model, (unsigned int)__shfl_xor((int)diag_model, o));
+        diag_exact = max(diag_exact, (unsigned int)__shfl_xor((int)diag_exact, o));
+        diag_both = max(diag_both, (unsigned int)__shfl_xor((int)diag_both, o));
+        diag_sum += (unsigned int)__shfl_xor((int)diag_sum, o);
+    }
     if (g_vr_timeline && (threadIdx.x & 63) == 0) {
         const unsigned long long wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
         unsigned int hw;
@@ -688,7 +787,9 @@ __global__ __launch_bounds__(256) void k_march_fast(VolumeView vol, FrameParams 
         g_vr_timeline[wave_id * 4 + 0] = diag_t0;
         g_vr_timeline[wave_id * 4 + 1] = wall_clock64();
         g_vr_timeline[wave_id * 4 + 2] = ((unsigned long long)xcc << 32) | hw;
-        g_vr_timeline[wave_id * 4 + 3] = 0;
+        g_vr_timeline[wave_id * 4 + 3] = (unsigned long long)diag_rounds | ((unsigned long long)diag_model << 12) |
+                                         ((unsigned long long)diag_exact << 24) | ((unsigned long long)diag_both << 36) |
+                                         ((unsigned long long)diag_sum << 48);
     }
 #endif
 }
@@ -716,21 +817,22 @@ __global__ __launch_bounds__(256) void k_march_long(VolumeView vol, FrameParams 
         const Ray r = make_ray(fp, px, py);          // identical in every lane
         const int last = fp.samples + 1;
         const float step = (r.tmax - r.tmin) / (float)(uint32_t)last;
-        const RayModel rm = ray_model(r, vol, step);
+        const RayModel rm = ray_model(r, vol, step, -1.0f);
         double F0 = e.F0, F1 = e.F1, F2 = e.F2, Tr = e.Tr;
         float S = e.S;
         int t = e.t;
         bool decided = false;
         uint32_t rgba = 0xff000000u;
         unsigned long long evaluated = 0;
-        while (t >= 1 && !decided) {
-            const int n = empty_span(vol, rm, t, -1.0f);   // wave-uniform
+        if (t > rm.t_first) t = rm.t_first;
+        while (t >= rm.t_stop && !decided) {
+            const int n = empty_span(vol, rm, t);   // wave-uniform
             if (n > 0) {
                 t -= n;
                 continue;
             }
             const int tt = t - lane;
-            bool fetch = tt >= 1;
+            bool fetch = tt >= rm.t_stop;
             Cell c;
             uint32_t brick = 0;
             if (fetch) {
