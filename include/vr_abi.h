@@ -152,6 +152,69 @@ int vr_count_hit_rays(vr_ctx *ctx, int width, int height, int x0, int y0, int x1
 /* Synthetic CT phantom used as measurement input (no counterpart in the reference): n^3 voxels
  * written to device memory, then usable with vr_upload_volume_device.  d_out: n^3 * dtype bytes. */
 int vr_phantom_generate_device(vr_ctx *ctx, void *d_out, int dtype, int n, uint32_t seed);
+/* The voxels [lo, hi) of the same n^3 phantom, x fastest: what one GPU of a sort-last split holds. */
+int vr_phantom_generate_box_device(vr_ctx *ctx, void *d_out, int dtype, int n, const int lo[3], const int hi[3],
+                                   uint32_t seed);
+
+/* ---- Sort-last rendering: the volume split over several GPUs -------------------------------------
+ * No counterpart in the reference, which renders on one GPU from one 3-D image (main.cpp:244-258);
+ * the frame produced is still the one VolumeRendering.comp defines.  The volume's grid of 8^3
+ * bricks (vr_brick_grid) is cut into boxes, one per context.  Tap t of a ray belongs to the box
+ * holding the low corner of its filter footprint, so every tap of the shader loop
+ * (VolumeRendering.comp:184-201) is evaluated by exactly one context, with the arithmetic of the
+ * single-GPU path.  A frame is made in four steps:
+ *   1. vr_render_partial on every context: per pixel 5 floats (F0, F1, F2, Tr, S) - colour sum,
+ *      transmittance and rounding-bound weight of the box's taps taken front to back;
+ *   2. the partial images are exchanged and merged in visibility order, either pairwise
+ *      (vr_composite_pair, binary swap) or all at once (vr_composite_ordered, direct send);
+ *   3. vr_decide_partials turns merged partials into RGBA8 and lists the pixels whose bytes the
+ *      merged numbers cannot decide (a rounding boundary inside the error interval);
+ *   4. those pixels are re-marched in the shader's order, the float colour handed from box to box
+ *      back to front: for stage = 0 .. boxes-1 every context calls vr_chain_stage and the outputs
+ *      are summed over the contexts (all but one are zero) to give the next stage's input;
+ *      vr_store_chain then writes their bytes.
+ * Pixels are addressed by their row-major index in the width x height frame; a span may run past
+ * the last pixel (padding, rendered as misses).  All pointers named d_* are device pointers on the
+ * context's GPU, all calls are asynchronous on the context's stream.  Camera, transfer function and
+ * sampling must be set identically on all contexts. */
+
+/* Bricks per axis of an nx x ny x nz volume. */
+int vr_brick_grid(int nx, int ny, int nz, int bricks[3]);
+/* Voxel box [voxel_lo, voxel_hi) the bricks [brick_lo, brick_hi) store (their 8^3 cells plus a
+ * one-voxel apron, clipped to the volume): what vr_upload_subvolume_device expects. */
+int vr_subvolume_voxels(int nx, int ny, int nz, const int brick_lo[3], const int brick_hi[3], int voxel_lo[3],
+                        int voxel_hi[3]);
+/* Like vr_upload_volume_device for the box [brick_lo, brick_hi) of the nx x ny x nz volume's brick
+ * grid: d_voxels holds only the voxels vr_subvolume_voxels names, x fastest.  max_value must be the
+ * maximum of the whole volume (> 0): main.cpp:161-164 divides every voxel by it.  Afterwards the
+ * context renders with vr_render_partial only. */
+int vr_upload_subvolume_device(vr_ctx *ctx, const void *d_voxels, int dtype, int nx, int ny, int nz,
+                               const int brick_lo[3], const int brick_hi[3], float max_value);
+/* Step 1.  out: width*height*5 floats, host (synchronous) or device pointer.  Also valid on a
+ * context holding the whole volume (one box). */
+int vr_render_partial(vr_ctx *ctx, int width, int height, float *out, int out_is_device);
+/* Step 2, pairwise: the boxes (or unions of boxes) behind d_mine and d_theirs are separated by a
+ * plane normal to `axis` (0 x, 1 y, 2 z in voxel index order); mine_is_low != 0 when d_mine's lies
+ * on the side of the smaller indices.  count partials each, for pixels first_pixel ... */
+int vr_composite_pair(vr_ctx *ctx, int width, int height, uint64_t first_pixel, uint64_t count, const float *d_mine,
+                      const float *d_theirs, int axis, int mine_is_low, float *d_out);
+/* Step 2, all at once: d_parts holds one image of count partials per slot; d_slot_of_box[(bz *
+ * grid[1] + by) * grid[0] + bx] is the slot with the image of box (bx, by, bz) of the box grid. */
+int vr_composite_ordered(vr_ctx *ctx, int width, int height, uint64_t first_pixel, uint64_t count,
+                         const float *d_parts, const int *d_slot_of_box, const int grid[3], float *d_out);
+/* Step 3.  d_out_rgba8: count*4 bytes; d_undecided: room for count pixel indices;
+ * d_undecided_count: one uint32 (cleared by the call). */
+int vr_decide_partials(vr_ctx *ctx, int width, int height, uint64_t first_pixel, uint64_t count,
+                       const float *d_partials, uint8_t *d_out_rgba8, uint32_t *d_undecided,
+                       uint32_t *d_undecided_count);
+/* Step 4.  d_pixels: count frame pixel indices (the same list on every context); d_colour_in /
+ * d_colour_out: count float4 (rgb + unused); box: this context's position in the box grid. */
+int vr_chain_stage(vr_ctx *ctx, int width, int height, const uint32_t *d_pixels, uint64_t count,
+                   const float *d_colour_in, float *d_colour_out, int stage, const int grid[3], const int box[3]);
+/* Writes the RGBA8 value (imageStore, VolumeRendering.comp:205) of those of the count listed
+ * pixels that fall into [first_pixel, first_pixel + pixel_count) to d_out_rgba8[pixel - first_pixel]. */
+int vr_store_chain(vr_ctx *ctx, const uint32_t *d_pixels, const float *d_colour, uint64_t count,
+                   uint64_t first_pixel, uint64_t pixel_count, uint8_t *d_out_rgba8);
 
 #ifdef __cplusplus
 }

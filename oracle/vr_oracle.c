@@ -550,6 +550,143 @@ uint64_t vro_count_hits(const float location[4], const float to_world[16],
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Sort-last checkers: the shader loop restricted to the taps of one box of bricks.
+ * ---------------------------------------------------------------------------------------- */
+
+typedef struct { float rgba[4]; int owned; } tap_t;
+
+/* Tap t of a ray (VolumeRendering.comp:185-188, 193) and whether the box owns it. */
+static inline tap_t eval_tap(const sampler_state *s, const ray_t *r, float step, uint32_t t,
+                             const int lo[3], const int hi[3])
+{
+    tap_t o;
+    const float len = r->tmax - (float)t * step;
+    const float u = fabsf((r->o[0] + len * r->d[0]) - -0.5f);
+    const float v = fabsf((r->o[1] + len * r->d[1]) - -0.5f);
+    const float w = fabsf((r->o[2] + len * r->d[2]) - 0.0f);
+    const int cx = safe_index(floorf(u * s->fx - 0.5f), s->nx) + 2;
+    const int cy = safe_index(floorf(v * s->fy - 0.5f), s->ny) + 2;
+    const int cz = safe_index(floorf(w * s->fz - 0.5f), s->nz) + 2;
+    o.owned = cx >= 8 * lo[0] && cx < 8 * hi[0] && cy >= 8 * lo[1] && cy < 8 * hi[1] &&
+              cz >= 8 * lo[2] && cz < 8 * hi[2];
+    o.rgba[0] = o.rgba[1] = o.rgba[2] = o.rgba[3] = 0.0f;
+    if (o.owned) sample_tf(s, sample_volume(s, u, v, w), o.rgba);
+    return o;
+}
+
+static sampler_state make_sampler(const float *volume, uint32_t nx, uint32_t ny, uint32_t nz,
+                                  const float *lut, const float tf_border[4])
+{
+    sampler_state s;
+    s.vol = volume; s.nx = (int)nx; s.ny = (int)ny; s.nz = (int)nz;
+    s.fx = (float)nx; s.fy = (float)ny; s.fz = (float)nz;
+    s.lut = lut;
+    memcpy(s.border, tf_border, sizeof s.border);
+    return s;
+}
+
+void vro_render_partial(const float *volume, uint32_t nx, uint32_t ny, uint32_t nz,
+                        const float *lut, const float tf_border[4],
+                        const float location[4], const float to_world[16],
+                        uint32_t width, uint32_t height, uint32_t samples,
+                        const int brick_lo[3], const int brick_hi[3], float *out, int threads)
+{
+    const sampler_state s = make_sampler(volume, nx, ny, nz, lut, tf_border);
+    const double cut = 0x1p-40;
+#ifdef _OPENMP
+    if (threads <= 0) threads = omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+#endif
+    for (uint32_t py = 0; py < height; py++)
+        for (uint32_t px = 0; px < width; px++) {
+            float *o = out + ((size_t)py * width + px) * 5;
+            o[0] = o[1] = o[2] = o[3] = o[4] = 0.0f;
+            const ray_t r = make_ray(location, to_world, (int)px, (int)py);
+            if (!r.hit) continue;
+            const float step = (r.tmax - r.tmin) / (float)(samples + 1);
+            double F[3] = { 0.0, 0.0, 0.0 }, Tr = 1.0;
+            float S = 0.0f;
+            for (uint32_t t = samples + 1; t >= 1 && !(Tr < cut); t--) {
+                const tap_t tap = eval_tap(&s, &r, step, t, brick_lo, brick_hi);
+                if (!tap.owned || tap.rgba[3] == 0.0f) continue;
+                const double a = (double)tap.rgba[3], w = Tr * a;
+                for (int c = 0; c < 3; c++) F[c] = fma(w, (double)tap.rgba[c], F[c]);
+                S += (float)Tr;
+                Tr = Tr * (1.0 - a);
+            }
+            if (!(Tr < cut)) {
+                const tap_t tap = eval_tap(&s, &r, step, 0, brick_lo, brick_hi);
+                if (tap.owned) {
+                    for (int c = 0; c < 3; c++) F[c] = fma(Tr, (double)tap.rgba[c], F[c]);
+                    Tr = 0.0;
+                }
+            }
+            o[0] = (float)F[0]; o[1] = (float)F[1]; o[2] = (float)F[2]; o[3] = (float)Tr; o[4] = S;
+        }
+}
+
+static inline void march_direction(const ray_t *r, float step, const sampler_state *s, int up[3])
+{
+    up[0] = -(step * r->d[0]) * s->fx >= 0.0f;
+    up[1] = -(step * r->d[1]) * s->fy >= 0.0f;
+    up[2] = (step * r->d[2]) * s->fz >= 0.0f;
+}
+
+void vro_march_direction(const float location[4], const float to_world[16],
+                         uint32_t width, uint32_t height, uint32_t samples,
+                         uint32_t nx, uint32_t ny, uint32_t nz, uint8_t *out)
+{
+    sampler_state s;
+    memset(&s, 0, sizeof s);
+    s.fx = (float)nx; s.fy = (float)ny; s.fz = (float)nz;
+    for (uint32_t py = 0; py < height; py++)
+        for (uint32_t px = 0; px < width; px++) {
+            const ray_t r = make_ray(location, to_world, (int)px, (int)py);
+            const float step = (r.tmax - r.tmin) / (float)(samples + 1);
+            int up[3];
+            march_direction(&r, step, &s, up);
+            uint8_t *o = out + ((size_t)py * width + px) * 4;
+            o[0] = (uint8_t)up[0]; o[1] = (uint8_t)up[1]; o[2] = (uint8_t)up[2]; o[3] = (uint8_t)r.hit;
+        }
+}
+
+void vro_chain_stage(const float *volume, uint32_t nx, uint32_t ny, uint32_t nz,
+                     const float *lut, const float tf_border[4],
+                     const float location[4], const float to_world[16],
+                     uint32_t width, uint32_t height, uint32_t samples,
+                     const int brick_lo[3], const int brick_hi[3],
+                     const uint32_t *pixels, uint32_t count, const float *colour_in, float *colour_out,
+                     int stage, const int grid[3], const int box[3])
+{
+    const sampler_state s = make_sampler(volume, nx, ny, nz, lut, tf_border);
+    for (uint32_t e = 0; e < count; e++) {
+        float *o = colour_out + (size_t)e * 4;
+        o[0] = o[1] = o[2] = o[3] = 0.0f;
+        const uint32_t pixel = pixels[e];
+        if (pixel >= width * height) continue;
+        const ray_t r = make_ray(location, to_world, (int)(pixel % width), (int)(pixel / width));
+        const float step = (r.tmax - r.tmin) / (float)(samples + 1);
+        int up[3], m[3];
+        march_direction(&r, step, &s, up);
+        for (int k = 0; k < 3; k++) m[k] = up[k] ? box[k] : grid[k] - 1 - box[k];
+        if ((m[2] * grid[1] + m[1]) * grid[0] + m[0] != stage) continue;
+        float C[3] = { colour_in[e * 4], colour_in[e * 4 + 1], colour_in[e * 4 + 2] };
+        if (r.hit)
+            for (uint32_t t = 0; t <= samples + 1; t++) {
+                const tap_t tap = eval_tap(&s, &r, step, t, brick_lo, brick_hi);
+                if (!tap.owned) continue;
+                if (t == 0) {
+                    C[0] = tap.rgba[0]; C[1] = tap.rgba[1]; C[2] = tap.rgba[2];
+                } else {
+                    const float a = tap.rgba[3], ia = 1.0f - a;
+                    for (int c = 0; c < 3; c++) C[c] = a * tap.rgba[c] + ia * C[c];
+                }
+            }
+        o[0] = C[0]; o[1] = C[1]; o[2] = C[2];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
  * Synthetic phantom (measurement input of this build, not part of the reference).
  * 3-D Shepp-Logan head: ten ellipsoids, Kak-Slaney geometry, "modified" contrast expressed in
  * tenths so the sum is an exact integer.  Voxel centres of [-1,1]^3.  Inside the outer

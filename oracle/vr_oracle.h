@@ -87,6 +87,40 @@ uint64_t vro_count_hits_rows(const float location[4], const float to_world[16],
  * 3-D Shepp-Logan, n^3 voxels, dtype_bytes 1 or 2, little-endian raw, x fastest. */
 void vro_phantom(void *out, uint32_t n, int dtype_bytes, uint32_t seed);
 
+/* ---- Checkers for the sort-last split (the split itself has no counterpart in the reference; these
+ * restate the shader loop, VolumeRendering.comp:183-202, restricted to the taps of one box).
+ * The volume's padded cell grid (cell = voxel index + 2) is cut into cubes of 8 cells ("bricks");
+ * a box is the brick range [brick_lo, brick_hi).  A tap belongs to the box that holds the low corner
+ * cell of its trilinear footprint. */
+
+/* Per pixel five floats (F0, F1, F2, Tr, S): the box's taps taken front to back, F = sum of
+ * T a c (double accumulation), Tr = product of (1 - a), S = sum of T over taps with a != 0; the
+ * owner of tap 0 adds Tr * c0 and sets Tr = 0; marching stops below Tr = 2^-40; all zero for a
+ * ray that misses the volume. */
+void vro_render_partial(const float *volume, uint32_t nx, uint32_t ny, uint32_t nz,
+                        const float *lut, const float tf_border[4],
+                        const float location[4], const float to_world[16],
+                        uint32_t width, uint32_t height, uint32_t samples,
+                        const int brick_lo[3], const int brick_hi[3], float *out, int threads);
+
+/* Per pixel four bytes: whether the x, y, z voxel index grows with the tap index (towards the
+ * eye), and whether the ray hits the volume. */
+void vro_march_direction(const float location[4], const float to_world[16],
+                         uint32_t width, uint32_t height, uint32_t samples,
+                         uint32_t nx, uint32_t ny, uint32_t nz, uint8_t *out);
+
+/* One stage of the back-to-front pass over listed pixels: boxes form a grid[0] x grid[1] x grid[2]
+ * grid, this one at `box`; for pixels whose back-to-front rank of this box (lexicographic, z
+ * slowest, axes the ray descends along mirrored) equals stage, blend the box's taps in the
+ * shader's order over colour_in (3 floats + 1 unused per pixel), else write zeros. */
+void vro_chain_stage(const float *volume, uint32_t nx, uint32_t ny, uint32_t nz,
+                     const float *lut, const float tf_border[4],
+                     const float location[4], const float to_world[16],
+                     uint32_t width, uint32_t height, uint32_t samples,
+                     const int brick_lo[3], const int brick_hi[3],
+                     const uint32_t *pixels, uint32_t count, const float *colour_in, float *colour_out,
+                     int stage, const int grid[3], const int box[3]);
+
 int vro_threads(void);
 
 #ifdef __cplusplus

@@ -63,6 +63,15 @@ def lib():
         L.vro_phantom.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32]
         L.vro_phantom.restype = None
         L.vro_threads.restype = C.c_int
+        i3 = C.POINTER(C.c_int)
+        u32 = C.c_uint32
+        L.vro_render_partial.argtypes = [fp, u32, u32, u32, fp, fp, fp, fp, u32, u32, u32, i3, i3, fp, C.c_int]
+        L.vro_render_partial.restype = None
+        L.vro_march_direction.argtypes = [fp, fp, u32, u32, u32, u32, u32, u32, C.c_void_p]
+        L.vro_march_direction.restype = None
+        L.vro_chain_stage.argtypes = [fp, u32, u32, u32, fp, fp, fp, fp, u32, u32, u32, i3, i3,
+                                      C.c_void_p, u32, fp, fp, C.c_int, i3, i3]
+        L.vro_chain_stage.restype = None
         _lib = L
     return _lib
 
@@ -169,3 +178,48 @@ def phantom(n, dtype=np.uint16, seed=0x5EED1234):
 
 def threads():
     return int(lib().vro_threads())
+
+
+def _i3(v):
+    return (C.c_int * 3)(*[int(x) for x in v])
+
+
+def render_partial(volume, lut, location, to_world, width, height, samples, brick_lo, brick_hi,
+                   border=(0.0, 0.0, 0.0, 0.0), threads=0):
+    """Sort-last partial result of the brick box [brick_lo, brick_hi) (x, y, z): [height*width, 5]."""
+    volume = np.ascontiguousarray(volume, np.float32)
+    nz, ny, nx = volume.shape
+    lut = np.ascontiguousarray(lut, np.float32).ravel()
+    loc = np.ascontiguousarray(location, np.float32).ravel()
+    m = np.ascontiguousarray(to_world, np.float32).ravel()
+    b = np.asarray(border, np.float32)
+    out = np.zeros((height * width, 5), np.float32)
+    lib().vro_render_partial(_fp(volume), nx, ny, nz, _fp(lut), _fp(b), _fp(loc), _fp(m), width, height,
+                             samples, _i3(brick_lo), _i3(brick_hi), _fp(out), threads)
+    return out
+
+
+def march_direction(location, to_world, width, height, samples, dims):
+    """[height*width, 4] uint8: x, y, z index grows towards the eye; ray hits.  dims = (nx, ny, nz)."""
+    loc = np.ascontiguousarray(location, np.float32).ravel()
+    m = np.ascontiguousarray(to_world, np.float32).ravel()
+    out = np.zeros((height * width, 4), np.uint8)
+    lib().vro_march_direction(_fp(loc), _fp(m), width, height, samples, dims[0], dims[1], dims[2], out.ctypes.data)
+    return out
+
+
+def chain_stage(volume, lut, location, to_world, width, height, samples, brick_lo, brick_hi, pixels,
+                colour_in, stage, grid, box, border=(0.0, 0.0, 0.0, 0.0)):
+    volume = np.ascontiguousarray(volume, np.float32)
+    nz, ny, nx = volume.shape
+    lut = np.ascontiguousarray(lut, np.float32).ravel()
+    loc = np.ascontiguousarray(location, np.float32).ravel()
+    m = np.ascontiguousarray(to_world, np.float32).ravel()
+    b = np.asarray(border, np.float32)
+    pixels = np.ascontiguousarray(pixels, np.uint32)
+    cin = np.ascontiguousarray(colour_in, np.float32)
+    out = np.zeros((pixels.size, 4), np.float32)
+    lib().vro_chain_stage(_fp(volume), nx, ny, nz, _fp(lut), _fp(b), _fp(loc), _fp(m), width, height, samples,
+                          _i3(brick_lo), _i3(brick_hi), pixels.ctypes.data, pixels.size, _fp(cin), _fp(out),
+                          stage, _i3(grid), _i3(box))
+    return out

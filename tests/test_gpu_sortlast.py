@@ -1,0 +1,303 @@
+"""GPU tests of the sort-last path: every kernel is reached through the C ABI (libvr_hip.so).
+
+One GPU stands in for several: each box of the split gets a context of its own on the same card.
+The frame assembled from the boxes must equal, byte for byte, the frame a single context renders
+from the whole volume, which the other GPU tests pin to the checker; the per-box partial results
+are compared with the checker's directly."""
+import math
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import conftest as cf
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def vr():
+    import vulkanrenderer_amd as m
+    return m
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+    assert t.cuda.is_available()
+    return t
+
+
+def make_boxes(vr, torch, vox, grid, graphs=cf.TF_GRAPHS, samples=60, border=(0, 0, 0, 0)):
+    """One context per box of `grid`, each holding its part of the host volume `vox`."""
+    from vulkanrenderer_amd import sortlast as sl
+    ctxs = []
+    for rank in range(grid[0] * grid[1] * grid[2]):
+        c = vr.VolumeRenderer(0)
+        sl.upload_box_of(c, vox, grid, sl.box_of_rank(rank, grid), "cuda")
+        c.update_transfer_function(graphs, reset_state=True)
+        c.set_sampling(samples, border)
+        ctxs.append(c)
+    return ctxs
+
+
+def sort_last_frame(vr, torch, ctxs, grid, w, h, schedule="ordered"):
+    """The four steps of a sort-last frame, the contexts taking turns on one GPU."""
+    from vulkanrenderer_amd import sortlast as sl
+    world = len(ctxs)
+    n = w * h
+    f32 = dict(dtype=torch.float32, device="cuda")
+    parts = torch.zeros((world, n, 5), **f32)
+    merged = torch.zeros((n, 5), **f32)
+    rgba = torch.zeros((n, 4), dtype=torch.uint8, device="cuda")
+    todo = torch.zeros(n, dtype=torch.int32, device="cuda")
+    count = torch.zeros(1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()        # torch's stream and the contexts' streams are ordered by hand here
+    for r, c in enumerate(ctxs):
+        c.render_partial(w, h, parts[r].data_ptr())
+        c.synchronize()
+    c0 = ctxs[0]
+    if schedule == "ordered":
+        slots = torch.arange(world, dtype=torch.int32, device="cuda")
+        c0.composite_ordered(w, h, 0, n, parts.data_ptr(), slots.data_ptr(), grid, merged.data_ptr())
+    else:
+        # pairwise merges in binary-swap order, all pixels at every node
+        held = [parts[r] for r in range(world)]
+        for rnd, axis in enumerate(sl.swap_rounds(world, grid)):
+            nxt = {}
+            for r in range(world):
+                if r & ((2 << rnd) - 1):       # only the lowest rank of each merged group carries on
+                    continue
+                out = torch.empty((n, 5), **f32)
+                c0.composite_pair(w, h, 0, n, held[r].data_ptr(), held[r | (1 << rnd)].data_ptr(), axis, 1, out.data_ptr())
+                nxt[r] = out
+            held = nxt
+        c0.synchronize()
+        merged = held[0]
+    c0.decide_partials(w, h, 0, n, merged.data_ptr(), rgba.data_ptr(), todo.data_ptr(), count.data_ptr())
+    c0.synchronize()
+    m = int(count.item())
+    if m:
+        pixels = todo[:m].contiguous()
+        colour = torch.zeros((m, 4), **f32)
+        for stage in range(world):
+            total = torch.zeros((m, 4), **f32)
+            torch.cuda.synchronize()
+            for r, c in enumerate(ctxs):
+                out = torch.empty((m, 4), **f32)
+                c.chain_stage(w, h, pixels.data_ptr(), m, colour.data_ptr(), out.data_ptr(), stage, grid, sl.box_of_rank(r, grid))
+                c.synchronize()
+                total += out
+            torch.cuda.synchronize()
+            colour = total
+        c0.store_chain(pixels.data_ptr(), colour.data_ptr(), m, 0, n, rgba.data_ptr())
+        c0.synchronize()
+    return rgba.cpu().numpy().reshape(h, w, 4), m, parts.cpu().numpy(), merged.cpu().numpy()
+
+
+def whole_frame(vr, vox, cam, w, h, samples, graphs=cf.TF_GRAPHS, border=(0, 0, 0, 0), mode=1):
+    with vr.VolumeRenderer(0) as c:
+        c.upload_volume(vox)
+        c.update_transfer_function(graphs, reset_state=True)
+        c.set_sampling(samples, border)
+        c.set_camera(*cam)
+        c.set_mode(mode)
+        return c.render(w, h)
+
+
+@pytest.mark.parametrize("dtype,n,grid,schedule", [
+    (np.uint16, 48, (2, 2, 2), "ordered"),
+    (np.uint16, 48, (2, 2, 2), "pairs"),
+    (np.uint8, 40, (3, 1, 2), "ordered"),
+    (np.uint8, 40, (4, 1, 1), "pairs"),
+    (np.uint16, 37, (1, 1, 1), "ordered"),
+])
+def test_boxes_assemble_the_single_context_frame(vr, torch, oracle, dtype, n, grid, schedule):
+    vox = oracle.phantom(n, dtype)
+    ctxs = make_boxes(vr, torch, vox, grid, samples=90)
+    try:
+        vol, _ = oracle.normalize(vox)
+        lut = np.zeros((256, 4), np.float32)
+        oracle.lut_update(lut, cf.TF_GRAPHS)
+        for cname, cam in cf.CAMERAS.items():
+            for c in ctxs:
+                c.set_camera(*cam)
+            w, h = 72, 56
+            got, remarched, parts, merged = sort_last_frame(vr, torch, ctxs, grid, w, h, schedule)
+            want = whole_frame(vr, vox, cam, w, h, 90)
+            assert np.array_equal(got, want), (cname, cf.frame_report(got, want))
+            vp, m = oracle.camera(cam[0], cam[1], w, h)
+            assert np.array_equal(got, oracle.render(vol, lut, vp[4:8], m, w, h, 90)), cname
+            assert remarched < 0.05 * w * h
+            # the partial results themselves, box by box, against the checker's
+            from vulkanrenderer_amd import sortlast as sl
+            bricks = vr.brick_grid(n, n, n)
+            for r in range(len(ctxs)):
+                lo, hi = sl.brick_box(bricks, grid, sl.box_of_rank(r, grid))
+                ref = oracle.render_partial(vol, lut, vp[4:8], m, w, h, 90, lo, hi)
+                assert np.allclose(parts[r], ref, rtol=2e-6, atol=1e-7), (cname, r, np.abs(parts[r] - ref).max())
+            assert np.all(merged[:, 3] <= 1e-9)          # every hit ray reached its back tap's owner
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_tables_the_interval_argument_does_not_cover(vr, torch, oracle):
+    # alpha above 1: partial sums mean nothing, every hit pixel must go through the box-to-box re-march
+    graphs = [cf.TF_GRAPHS[0], cf.TF_GRAPHS[1], cf.TF_GRAPHS[2], [(0, 0.0), (120, 0.0), (300, 0.4), (483, 1.7)]]
+    vox = oracle.phantom(32, np.uint8)
+    grid = (2, 1, 2)
+    ctxs = make_boxes(vr, torch, vox, grid, graphs=graphs, samples=50)
+    try:
+        cam = cf.CAMERAS["h30_v20"]
+        for c in ctxs:
+            c.set_camera(*cam)
+        got, remarched, _, _ = sort_last_frame(vr, torch, ctxs, grid, 48, 40)
+        vol, _ = oracle.normalize(vox)
+        lut = np.zeros((256, 4), np.float32)
+        oracle.lut_update(lut, graphs)
+        vp, m = oracle.camera(cam[0], cam[1], 48, 40)
+        assert remarched == oracle.count_hits(vp[4:8], m, 48, 40)
+        assert np.array_equal(got, oracle.render(vol, lut, vp[4:8], m, 48, 40, 50))
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_opaque_border_and_noise_volume(vr, torch, oracle):
+    rng = np.random.default_rng(5)
+    vox = rng.integers(0, 3000, size=(19, 33, 26)).astype(np.uint16)
+    grid = (2, 2, 1)
+    for border in ((0, 0, 0, 1), (0.2, 0.4, 0.6, 0.3)):
+        ctxs = make_boxes(vr, torch, vox, grid, samples=70, border=border)
+        try:
+            cam = cf.CAMERAS["hm135_vm60"]
+            for c in ctxs:
+                c.set_camera(*cam)
+            got, _, _, _ = sort_last_frame(vr, torch, ctxs, grid, 64, 48)
+            vol, _ = oracle.normalize(vox)
+            lut = np.zeros((256, 4), np.float32)
+            oracle.lut_update(lut, cf.TF_GRAPHS)
+            vp, m = oracle.camera(cam[0], cam[1], 64, 48)
+            assert np.array_equal(got, oracle.render(vol, lut, vp[4:8], m, 64, 48, 70, border=border)), border
+        finally:
+            for c in ctxs:
+                c.close()
+
+
+def test_phantom_box_equals_crop_of_the_phantom(vr, torch, oracle):
+    n = 45
+    full = oracle.phantom(n, np.uint16)
+    with vr.VolumeRenderer(0) as c:
+        for lo, hi in (((0, 0, 0), (n, n, n)), ((3, 10, 17), (40, 11, 45)), ((44, 44, 44), (45, 45, 45))):
+            ext = [h - l for l, h in zip(lo, hi)]
+            t = torch.zeros((ext[2], ext[1], ext[0]), dtype=torch.int16, device="cuda")
+            c.phantom_generate_box_device(t.data_ptr(), 2, n, lo, hi)
+            c.synchronize()
+            got = t.cpu().numpy().view(np.uint16)
+            assert np.array_equal(got, full[lo[2]:hi[2], lo[1]:hi[1], lo[0]:hi[0]]), (lo, hi)
+
+
+def test_sub_volume_contexts_refuse_whole_frame_calls(vr, torch, oracle):
+    vox = oracle.phantom(24, np.uint8)
+    ctxs = make_boxes(vr, torch, vox, (2, 1, 1))
+    try:
+        with pytest.raises(vr.VrError):
+            ctxs[0].render(32, 32)
+        with pytest.raises(vr.VrError):
+            ctxs[0].read_volume_normalized()
+        t = torch.zeros(1024, dtype=torch.uint8, device="cuda")
+        with pytest.raises(vr.VrError):      # brick box outside the grid
+            ctxs[0].upload_subvolume_device(t.data_ptr(), 1, 24, 24, 24, (0, 0, 0), (9, 1, 1), 255.0)
+        with pytest.raises(vr.VrError):      # the whole volume's maximum is required
+            ctxs[0].upload_subvolume_device(t.data_ptr(), 1, 24, 24, 24, (0, 0, 0), (1, 1, 1), 0.0)
+    finally:
+        for c in ctxs:
+            c.close()
+    assert vr.brick_grid(24, 24, 24) == (4, 4, 4) and vr.brick_grid(2048, 2048, 2048) == (257, 257, 257)
+    assert vr.subvolume_voxels(24, 24, 24, (0, 1, 3), (1, 3, 4)) == ((0, 6, 22), (7, 23, 24))
+
+
+# ---- several processes on one GPU, exchanges over gloo through host memory ----------------------
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n, width, height, samples, schedule, grid, cam, result_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import vulkanrenderer_amd as vr
+        from oracle import vr_oracle as o
+        from vulkanrenderer_amd import sortlast as sl
+        torch.cuda.set_device(0)
+        with vr.VolumeRenderer(0) as c:
+            sl.upload_phantom_box(c, n, 2, grid, sl.box_of_rank(rank, grid), "cuda")
+            c.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+            c.set_sampling(samples)
+            c.set_camera(*cam)
+            frame = sl.SortLastFrame(sl.HipEngine(c, width, height), width, height, rank, world, "cuda", grid=grid,
+                                     schedule=schedule, host_staging=True)
+            out = frame.render()
+            c.synchronize()
+            if rank == 0:
+                np.save(result_path, out.cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,schedule,grid", [(2, "binary_swap", (1, 2, 1)), (4, "direct_send", (2, 1, 2)),
+                                                 (8, "binary_swap", (2, 2, 2))])
+def test_processes_sharing_one_gpu(vr, torch, oracle, tmp_path, world, schedule, grid):
+    import torch.multiprocessing as mp
+    n, w, h, samples = 64, 96, 80, 120
+    cam = (math.radians(-70.0), math.radians(35.0))
+    path = str(tmp_path / "frame.npy")
+    mp.spawn(_worker, args=(world, _free_port(), n, w, h, samples, schedule, grid, cam, path), nprocs=world, join=True)
+    got = np.load(path)
+    want = whole_frame(vr, oracle.phantom(n, np.uint16), cam, w, h, samples)
+    assert want[..., :3].any()
+    assert np.array_equal(got, want), cf.frame_report(got, want)
+
+
+def test_full_size_split_equals_whole(vr, torch):
+    """1024^3 u16 at 1920x1080, eight boxes: the frame equals the single-context one."""
+    from vulkanrenderer_amd import sortlast as sl
+    n, w, h = 1024, 1920, 1080
+    samples = int(math.ceil(2 * math.sqrt(3) * n)) - 1
+    cam = (math.radians(40.0), math.radians(20.0))
+    grid = (2, 2, 2)
+    ctxs = []
+    try:
+        for r in range(8):
+            c = vr.VolumeRenderer(0)
+            sl.upload_phantom_box(c, n, 2, grid, sl.box_of_rank(r, grid), "cuda")
+            c.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+            c.set_sampling(samples)
+            c.set_camera(*cam)
+            ctxs.append(c)
+        got, remarched, _, _ = sort_last_frame(vr, torch, ctxs, grid, w, h)
+    finally:
+        for c in ctxs:
+            c.close()
+    with vr.VolumeRenderer(0) as c:
+        raw = torch.empty(n ** 3, dtype=torch.int16, device="cuda")
+        c.phantom_generate_device(raw.data_ptr(), 2, n)
+        c.upload_volume_device(raw.data_ptr(), 2, n, n, n)
+        del raw
+        c.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+        c.set_sampling(samples)
+        c.set_camera(*cam)
+        c.set_mode(vr.MODE_FAST)
+        want = c.render(w, h)
+    print("re-marched pixels: %d of %d" % (remarched, w * h))
+    assert want[..., :3].any()
+    assert np.array_equal(got, want), cf.frame_report(got, want)
+    assert remarched < 0.02 * w * h

@@ -25,8 +25,12 @@ ABI_SYMBOLS = (
     "vr_camera_uniforms",
     "vr_set_sampling", "vr_set_mode", "vr_render", "vr_render_rect", "vr_render_bands",
     "vr_band_rows", "vr_march_kernel_times", "vr_count_hit_rays",
-    "vr_phantom_generate_device",
+    "vr_phantom_generate_device", "vr_phantom_generate_box_device",
+    "vr_brick_grid", "vr_subvolume_voxels", "vr_upload_subvolume_device", "vr_render_partial",
+    "vr_composite_pair", "vr_composite_ordered", "vr_decide_partials", "vr_chain_stage",
+    "vr_store_chain",
 )
+PARTIAL_FLOATS = 5   # floats per pixel of a sort-last partial result: F0, F1, F2, Tr, S
 
 
 class CtrlPt(C.Structure):
@@ -97,6 +101,17 @@ def lib():
     L.vr_march_kernel_times.argtypes = [vp, fp, C.c_int, C.POINTER(C.c_int)]
     L.vr_count_hit_rays.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
     L.vr_phantom_generate_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_uint32]
+    i3, u64 = C.POINTER(C.c_int), C.c_uint64
+    L.vr_phantom_generate_box_device.argtypes = [vp, vp, C.c_int, C.c_int, i3, i3, C.c_uint32]
+    L.vr_brick_grid.argtypes = [C.c_int, C.c_int, C.c_int, i3]
+    L.vr_subvolume_voxels.argtypes = [C.c_int, C.c_int, C.c_int, i3, i3, i3, i3]
+    L.vr_upload_subvolume_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, i3, i3, C.c_float]
+    L.vr_render_partial.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
+    L.vr_composite_pair.argtypes = [vp, C.c_int, C.c_int, u64, u64, vp, vp, C.c_int, C.c_int, vp]
+    L.vr_composite_ordered.argtypes = [vp, C.c_int, C.c_int, u64, u64, vp, vp, i3, vp]
+    L.vr_decide_partials.argtypes = [vp, C.c_int, C.c_int, u64, u64, vp, vp, vp, vp]
+    L.vr_chain_stage.argtypes = [vp, C.c_int, C.c_int, vp, u64, vp, vp, C.c_int, i3, i3]
+    L.vr_store_chain.argtypes = [vp, vp, vp, u64, u64, u64, vp]
     for name in ABI_SYMBOLS:
         fn = getattr(L, name)
         if name not in ("vr_last_error", "vr_stream", "vr_control_point_intensity"):
@@ -133,6 +148,26 @@ def band_row_indices(height, part, parts):
     for band in range(part, (height + 15) // 16, parts):
         rows.extend(range(band * 16, min(height, band * 16 + 16)))
     return np.asarray(rows, np.int64)
+
+
+def _i3(v):
+    return (C.c_int * 3)(*[int(x) for x in v])
+
+
+def brick_grid(nx, ny, nz):
+    """Bricks per axis (x, y, z) of an nx x ny x nz volume."""
+    out = (C.c_int * 3)()
+    if lib().vr_brick_grid(nx, ny, nz, out) != 0:
+        raise VrError("vr_brick_grid: bad arguments")
+    return tuple(out)
+
+
+def subvolume_voxels(nx, ny, nz, brick_lo, brick_hi):
+    """Voxel box (lo, hi), each (x, y, z), that the bricks [brick_lo, brick_hi) store."""
+    lo, hi = (C.c_int * 3)(), (C.c_int * 3)()
+    if lib().vr_subvolume_voxels(nx, ny, nz, _i3(brick_lo), _i3(brick_hi), lo, hi) != 0:
+        raise VrError("vr_subvolume_voxels: bad arguments")
+    return tuple(lo), tuple(hi)
 
 
 def control_point_intensity(y, child_height):
@@ -292,3 +327,40 @@ class VolumeRenderer:
         self._check(lib().vr_render_rect(self._h, width, height, x0, y0, x1, y1, ptr, 1,
                                          C.byref(st) if stats else None))
         return st.as_dict() if stats else None
+
+    # --- sort-last: one box of the volume's brick grid per context (no reference counterpart) ---
+    def phantom_generate_box_device(self, ptr, dtype_bytes, n, lo, hi, seed=0x5EED1234):
+        self._check(lib().vr_phantom_generate_box_device(self._h, ptr, dtype_bytes, n, _i3(lo), _i3(hi), seed))
+
+    def upload_subvolume_device(self, ptr, dtype_bytes, nx, ny, nz, brick_lo, brick_hi, max_value):
+        self._check(lib().vr_upload_subvolume_device(self._h, ptr, dtype_bytes, nx, ny, nz, _i3(brick_lo),
+                                                     _i3(brick_hi), max_value))
+
+    def render_partial(self, width, height, ptr=None):
+        """Partial result of this context's box: (height*width, 5) floats.  With ptr (device memory)
+        the call is asynchronous and returns None."""
+        if ptr is not None:
+            self._check(lib().vr_render_partial(self._h, width, height, ptr, 1))
+            return None
+        out = np.empty((height * width, PARTIAL_FLOATS), np.float32)
+        self._check(lib().vr_render_partial(self._h, width, height, out.ctypes.data, 0))
+        return out
+
+    def composite_pair(self, width, height, first, count, mine, theirs, axis, mine_is_low, out):
+        self._check(lib().vr_composite_pair(self._h, width, height, first, count, mine, theirs, axis,
+                                            int(bool(mine_is_low)), out))
+
+    def composite_ordered(self, width, height, first, count, parts, slot_of_box, grid, out):
+        self._check(lib().vr_composite_ordered(self._h, width, height, first, count, parts, slot_of_box,
+                                               _i3(grid), out))
+
+    def decide_partials(self, width, height, first, count, partials, out_rgba8, undecided, undecided_count):
+        self._check(lib().vr_decide_partials(self._h, width, height, first, count, partials, out_rgba8,
+                                             undecided, undecided_count))
+
+    def chain_stage(self, width, height, pixels, count, colour_in, colour_out, stage, grid, box):
+        self._check(lib().vr_chain_stage(self._h, width, height, pixels, count, colour_in, colour_out, stage,
+                                         _i3(grid), _i3(box)))
+
+    def store_chain(self, pixels, colour, count, first, pixel_count, out_rgba8):
+        self._check(lib().vr_store_chain(self._h, pixels, colour, count, first, pixel_count, out_rgba8))

@@ -17,6 +17,7 @@
 
 #include "vr_camera.hpp"
 #include "vr_march.hpp"
+#include "vr_sortlast.hpp"
 
 struct vr_ctx {
     int device = 0;
@@ -40,6 +41,9 @@ struct vr_ctx {
     uint32_t *skip = nullptr;             // per brick: 2-bit code of the coarsest empty cube around it
     bool occupancy_dirty = true;
     int dtype = 0, nx = 0, ny = 0, nz = 0, nbx = 0, nby = 0, nbz = 0;
+    // sort-last: the bricks held are the box [brick_lo, brick_lo + (nbx, nby, nbz)) of the volume's grid
+    bool sub = false;
+    int brick_lo[3] = {0, 0, 0};
     float max_value = 0.0f, inv_hi = 0.0f, inv_lo = 0.0f;
 
     // transfer function
@@ -62,6 +66,8 @@ struct vr_ctx {
     vr::LutInfo *lut_info = nullptr;   // device
     uint32_t *frame = nullptr;         // device staging for host-pointer renders
     size_t frame_cap = 0;
+    float *partial = nullptr;          // device staging for host-pointer partial renders
+    size_t partial_cap = 0;
     uint32_t *queue = nullptr;         // pixels the fast march hands to the reference-order march
     size_t queue_cap = 0;
     vr::LongRay *long_queue = nullptr; // rays the lane march hands to the wave march
@@ -107,6 +113,8 @@ void release_volume(vr_ctx *ctx)
     ctx->occupancy_dirty = true;
     ctx->brick_count = 0;
     ctx->dtype = 0;
+    ctx->sub = false;
+    ctx->brick_lo[0] = ctx->brick_lo[1] = ctx->brick_lo[2] = 0;
 }
 
 vr::VolumeView view_of(const vr_ctx *ctx)
@@ -126,27 +134,67 @@ vr::VolumeView view_of(const vr_ctx *ctx)
     v.micro = ctx->micro;
     v.skip = ctx->skip;
     v.occ = ctx->occ;
+    v.ox = ctx->brick_lo[0] * vr::kBrick;
+    v.oy = ctx->brick_lo[1] * vr::kBrick;
+    v.oz = ctx->brick_lo[2] * vr::kBrick;
     return v;
 }
 
-// Re-tiles a linear device volume into bricks.  d_raw may be modified (byte swap) when
-// big_endian is set.  Frees nothing of the caller's.
-template <typename T>
-int ingest_device(vr_ctx *ctx, T *d_raw, int nx, int ny, int nz, float max_value, bool big_endian)
+int bricks_along(int voxels) { return (voxels + 2 * vr::kPad + vr::kBrick - 1) / vr::kBrick; }
+
+// Voxels [lo, hi) of an axis of `voxels` voxels that the bricks [b_lo, b_hi) store (apron included).
+void voxels_of_bricks(int voxels, int b_lo, int b_hi, int &lo, int &hi)
 {
-    const size_t count = (size_t)nx * ny * nz;
-    uint32_t *d_max = nullptr;
-    VR_HIP(ctx, hipMalloc(&d_max, sizeof(uint32_t)));
-    VR_HIP(ctx, hipMemsetAsync(d_max, 0, sizeof(uint32_t), ctx->stream));
-    const int blocks = (int)std::min<size_t>((count + 255) / 256, 256 * 16);
-    if (big_endian)
-        hipLaunchKernelGGL((vr::k_swap_max<T, true>), dim3(blocks), dim3(256), 0, ctx->stream, d_raw, count, d_max);
-    else
-        hipLaunchKernelGGL((vr::k_swap_max<T, false>), dim3(blocks), dim3(256), 0, ctx->stream, d_raw, count, d_max);
+    lo = std::max(0, b_lo * vr::kBrick - vr::kPad);
+    hi = std::min(voxels, b_hi * vr::kBrick - vr::kPad + 1);
+    if (hi < lo) hi = lo;
+}
+
+// Re-tiles a linear device volume into bricks.  d_raw may be modified (byte swap) when
+// big_endian is set.  Frees nothing of the caller's.  With a brick box (b_lo, b_hi not null) only
+// those bricks are built and d_raw holds just the voxels they store.
+template <typename T>
+int ingest_device(vr_ctx *ctx, T *d_raw, int nx, int ny, int nz, float max_value, bool big_endian, const int *b_lo = nullptr,
+                  const int *b_hi = nullptr)
+{
+    const int dims[3] = {nx, ny, nz};
+    int lo[3] = {0, 0, 0}, hi[3] = {bricks_along(nx), bricks_along(ny), bricks_along(nz)};
+    const bool sub = b_lo != nullptr;
+    if (sub)
+        for (int k = 0; k < 3; k++) {
+            if (b_lo[k] < 0 || b_hi[k] > hi[k] || b_lo[k] >= b_hi[k]) return fail(ctx, VR_ERR_ARG, "brick box outside the volume's brick grid");
+            lo[k] = b_lo[k];
+        }
+    if (sub)
+        for (int k = 0; k < 3; k++) hi[k] = b_hi[k];
+    if (sub && !(max_value > 0.0f)) return fail(ctx, VR_ERR_ARG, "a sub-volume needs the whole volume's maximum as max_value");
+    vr::BrickSource src;
+    int raw_ext[3];
+    for (int k = 0; k < 3; k++) {
+        int v_lo, v_hi;
+        voxels_of_bricks(dims[k], lo[k], hi[k], v_lo, v_hi);
+        src.b0[k] = lo[k];
+        src.v0[k] = v_lo;
+        raw_ext[k] = v_hi - v_lo;
+    }
+    src.rx = raw_ext[0];
+    src.ry = raw_ext[1];
+    const size_t count = (size_t)raw_ext[0] * raw_ext[1] * raw_ext[2];
+    if (count > 0 && !d_raw) return fail(ctx, VR_ERR_ARG, "null argument");
     uint32_t data_max = 0;
-    VR_HIP(ctx, hipMemcpyAsync(&data_max, d_max, sizeof data_max, hipMemcpyDeviceToHost, ctx->stream));
-    VR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    (void)hipFree(d_max);
+    if (count > 0) {
+        uint32_t *d_max = nullptr;
+        VR_HIP(ctx, hipMalloc(&d_max, sizeof(uint32_t)));
+        VR_HIP(ctx, hipMemsetAsync(d_max, 0, sizeof(uint32_t), ctx->stream));
+        const int blocks = (int)std::min<size_t>((count + 255) / 256, 256 * 16);
+        if (big_endian)
+            hipLaunchKernelGGL((vr::k_swap_max<T, true>), dim3(blocks), dim3(256), 0, ctx->stream, d_raw, count, d_max);
+        else
+            hipLaunchKernelGGL((vr::k_swap_max<T, false>), dim3(blocks), dim3(256), 0, ctx->stream, d_raw, count, d_max);
+        VR_HIP(ctx, hipMemcpyAsync(&data_max, d_max, sizeof data_max, hipMemcpyDeviceToHost, ctx->stream));
+        VR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(d_max);
+    }
 
     float mx = (float)data_max;  // main.cpp:144, exact for 16-bit values
     if (max_value > 0.0f) {
@@ -158,9 +206,11 @@ int ingest_device(vr_ctx *ctx, T *d_raw, int nx, int ny, int nz, float max_value
 
     release_volume(ctx);
     ctx->nx = nx; ctx->ny = ny; ctx->nz = nz;
-    ctx->nbx = (nx + 2 * vr::kPad + vr::kBrick - 1) / vr::kBrick;
-    ctx->nby = (ny + 2 * vr::kPad + vr::kBrick - 1) / vr::kBrick;
-    ctx->nbz = (nz + 2 * vr::kPad + vr::kBrick - 1) / vr::kBrick;
+    ctx->nbx = hi[0] - lo[0];
+    ctx->nby = hi[1] - lo[1];
+    ctx->nbz = hi[2] - lo[2];
+    ctx->sub = sub;
+    for (int k = 0; k < 3; k++) ctx->brick_lo[k] = lo[k];
     ctx->brick_count = (size_t)ctx->nbx * ctx->nby * ctx->nbz;
     if (ctx->brick_count >= (1ull << 31)) return fail(ctx, VR_ERR_ARG, "volume too large");
     ctx->dtype = (int)sizeof(T);
@@ -183,7 +233,7 @@ int ingest_device(vr_ctx *ctx, T *d_raw, int nx, int ny, int nz, float max_value
     ctx->occupancy_dirty = true;
     const unsigned brick_blocks = (unsigned)std::min<size_t>(ctx->brick_count, 1u << 20);
     hipLaunchKernelGGL((vr::k_build_bricks<T>), dim3(brick_blocks), dim3(256), 0, ctx->stream, (const T *)d_raw,
-                       (T *)ctx->bricks, ctx->cells, nx, ny, nz, ctx->nbx, ctx->nby, (uint32_t)ctx->brick_count);
+                       (T *)ctx->bricks, ctx->cells, nx, ny, nz, ctx->nbx, ctx->nby, (uint32_t)ctx->brick_count, src);
     VR_HIP(ctx, hipGetLastError());
     VR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return VR_OK;
@@ -336,6 +386,7 @@ int vr_destroy(vr_ctx *ctx)
     if (ctx->d_pts) (void)hipFree(ctx->d_pts);
     if (ctx->counters) (void)hipFree(ctx->counters);
     if (ctx->frame) (void)hipFree(ctx->frame);
+    if (ctx->partial) (void)hipFree(ctx->partial);
     if (ctx->queue) (void)hipFree(ctx->queue);
     if (ctx->long_queue) (void)hipFree(ctx->long_queue);
     if (ctx->lut_info) (void)hipFree(ctx->lut_info);
@@ -447,6 +498,7 @@ int vr_read_volume_normalized(vr_ctx *ctx, float *out)
 {
     if (!ctx || !out) return fail(ctx, VR_ERR_ARG, "null argument");
     if (!ctx->bricks) return fail(ctx, VR_ERR_STATE, "no volume uploaded");
+    if (ctx->sub) return fail(ctx, VR_ERR_STATE, "the context holds a sub-volume");
     if (int rc = bind(ctx)) return rc;
     const size_t count = (size_t)ctx->nx * ctx->ny * ctx->nz;
     float *d = nullptr;
@@ -587,6 +639,7 @@ static int render_impl(vr_ctx *ctx, int width, int height, int x0, int y0, int x
     if (!ctx || !out) return fail(ctx, VR_ERR_ARG, "null argument");
     if (parts < 1 || part < 0 || part >= parts) return fail(ctx, VR_ERR_ARG, "bad sort-first part");
     if (!ctx->bricks) return fail(ctx, VR_ERR_STATE, "no volume uploaded");
+    if (ctx->sub) return fail(ctx, VR_ERR_STATE, "the context holds a sub-volume: use vr_render_partial");
     if (width < 2 || height < 2 || width > 65536 || height > 65536) return fail(ctx, VR_ERR_ARG, "image size out of range");
     if (x0 < 0 || y0 < 0 || x1 > width || y1 > height || x0 >= x1 || y0 >= y1) return fail(ctx, VR_ERR_ARG, "bad pixel rectangle");
     if (int rc = bind(ctx)) return rc;
@@ -754,15 +807,209 @@ int vr_count_hit_rays(vr_ctx *ctx, int width, int height, int x0, int y0, int x1
 
 int vr_phantom_generate_device(vr_ctx *ctx, void *d_out, int dtype, int n, uint32_t seed)
 {
-    if (!ctx || !d_out) return fail(ctx, VR_ERR_ARG, "null argument");
+    const int lo[3] = {0, 0, 0}, hi[3] = {n, n, n};
+    return vr_phantom_generate_box_device(ctx, d_out, dtype, n, lo, hi, seed);
+}
+
+int vr_phantom_generate_box_device(vr_ctx *ctx, void *d_out, int dtype, int n, const int lo[3], const int hi[3], uint32_t seed)
+{
+    if (!ctx || !d_out || !lo || !hi) return fail(ctx, VR_ERR_ARG, "null argument");
     if (int rc = check_dims(ctx, dtype, n, n, n)) return rc;
+    vr::PhantomBox box;
+    for (int k = 0; k < 3; k++) {
+        if (lo[k] < 0 || hi[k] > n || lo[k] >= hi[k]) return fail(ctx, VR_ERR_ARG, "bad voxel box");
+        box.lo[k] = (uint32_t)lo[k];
+        box.ext[k] = (uint32_t)(hi[k] - lo[k]);
+    }
     if (int rc = bind(ctx)) return rc;
-    const size_t count = (size_t)n * n * n;
+    const size_t count = (size_t)box.ext[0] * box.ext[1] * box.ext[2];
     const int blocks = (int)std::min<size_t>((count + 255) / 256, 256 * 32);
     if (dtype == VR_DTYPE_U8)
-        hipLaunchKernelGGL((vr::k_phantom<uint8_t>), dim3(blocks), dim3(256), 0, ctx->stream, (uint8_t *)d_out, (uint32_t)n, 255u, seed);
+        hipLaunchKernelGGL((vr::k_phantom<uint8_t>), dim3(blocks), dim3(256), 0, ctx->stream, (uint8_t *)d_out, (uint32_t)n, 255u, seed, box);
     else
-        hipLaunchKernelGGL((vr::k_phantom<uint16_t>), dim3(blocks), dim3(256), 0, ctx->stream, (uint16_t *)d_out, (uint32_t)n, 65535u, seed);
+        hipLaunchKernelGGL((vr::k_phantom<uint16_t>), dim3(blocks), dim3(256), 0, ctx->stream, (uint16_t *)d_out, (uint32_t)n, 65535u, seed, box);
+    VR_HIP(ctx, hipGetLastError());
+    return VR_OK;
+}
+
+// ---- sort-last ---------------------------------------------------------------------------------------
+
+int vr_brick_grid(int nx, int ny, int nz, int bricks[3])
+{
+    if (!bricks || nx < 1 || ny < 1 || nz < 1) return VR_ERR_ARG;
+    bricks[0] = bricks_along(nx);
+    bricks[1] = bricks_along(ny);
+    bricks[2] = bricks_along(nz);
+    return VR_OK;
+}
+
+int vr_subvolume_voxels(int nx, int ny, int nz, const int brick_lo[3], const int brick_hi[3], int voxel_lo[3], int voxel_hi[3])
+{
+    if (!brick_lo || !brick_hi || !voxel_lo || !voxel_hi || nx < 1 || ny < 1 || nz < 1) return VR_ERR_ARG;
+    const int dims[3] = {nx, ny, nz};
+    for (int k = 0; k < 3; k++) {
+        if (brick_lo[k] < 0 || brick_hi[k] > bricks_along(dims[k]) || brick_lo[k] >= brick_hi[k]) return VR_ERR_ARG;
+        voxels_of_bricks(dims[k], brick_lo[k], brick_hi[k], voxel_lo[k], voxel_hi[k]);
+    }
+    return VR_OK;
+}
+
+int vr_upload_subvolume_device(vr_ctx *ctx, const void *d_voxels, int dtype, int nx, int ny, int nz, const int brick_lo[3],
+                               const int brick_hi[3], float max_value)
+{
+    if (!ctx || !brick_lo || !brick_hi) return fail(ctx, VR_ERR_ARG, "null argument");
+    if (int rc = check_dims(ctx, dtype, nx, ny, nz)) return rc;
+    if (int rc = bind(ctx)) return rc;
+    if (dtype == VR_DTYPE_U8) return ingest_device<uint8_t>(ctx, (uint8_t *)d_voxels, nx, ny, nz, max_value, false, brick_lo, brick_hi);
+    return ingest_device<uint16_t>(ctx, (uint16_t *)d_voxels, nx, ny, nz, max_value, false, brick_lo, brick_hi);
+}
+
+static int frame_params(vr_ctx *ctx, int width, int height, vr::FrameParams &fp)
+{
+    if (width < 2 || height < 2 || width > 65536 || height > 65536) return fail(ctx, VR_ERR_ARG, "image size out of range");
+    float pyramid[20];
+    if (int rc = vr_get_camera(ctx, width, height, pyramid, fp.m)) return rc;
+    std::memcpy(fp.loc, pyramid + 4, sizeof fp.loc);
+    fp.width = width; fp.height = height;
+    fp.x0 = 0; fp.y0 = 0; fp.x1 = width; fp.y1 = height;
+    fp.samples = ctx->samples;
+    fp.part = 0;
+    fp.parts = 1;
+    return VR_OK;
+}
+
+int vr_render_partial(vr_ctx *ctx, int width, int height, float *out, int out_is_device)
+{
+    if (!ctx || !out) return fail(ctx, VR_ERR_ARG, "null argument");
+    if (!ctx->bricks) return fail(ctx, VR_ERR_STATE, "no volume uploaded");
+    if (int rc = bind(ctx)) return rc;
+    vr::FrameParams fp;
+    if (int rc = frame_params(ctx, width, height, fp)) return rc;
+    const size_t pixels = (size_t)width * height;
+    float *d_out = out;
+    if (!out_is_device) {
+        if (pixels > ctx->partial_cap) {
+            if (ctx->partial) (void)hipFree(ctx->partial);
+            ctx->partial = nullptr;
+            ctx->partial_cap = 0;
+            VR_HIP(ctx, hipMalloc(&ctx->partial, pixels * vr::kPartial * sizeof(float)));
+            ctx->partial_cap = pixels;
+        }
+        d_out = ctx->partial;
+    }
+    if (int rc = refresh_occupancy(ctx)) return rc;
+    const int tiles = ((width + 7) / 8) * 2 * ((height + 15) / 16);
+    const vr::VolumeView vol = view_of(ctx);
+    const float4 border = make_float4(ctx->border[0], ctx->border[1], ctx->border[2], ctx->border[3]);
+    const float4 *lut = reinterpret_cast<const float4 *>(ctx->lut);
+    if (ctx->dtype == VR_DTYPE_U8)
+        hipLaunchKernelGGL((vr::k_march_partial<uint8_t>), dim3((unsigned)tiles), dim3(64), 0, ctx->stream, vol, fp, lut, border, d_out);
+    else
+        hipLaunchKernelGGL((vr::k_march_partial<uint16_t>), dim3((unsigned)tiles), dim3(64), 0, ctx->stream, vol, fp, lut, border, d_out);
+    VR_HIP(ctx, hipGetLastError());
+    if (!out_is_device) {
+        VR_HIP(ctx, hipMemcpyAsync(out, d_out, pixels * vr::kPartial * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        VR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return VR_OK;
+}
+
+static int pixel_span(vr_ctx *ctx, uint64_t first_pixel, uint64_t count)
+{
+    if (count == 0 || count > 0x7fffffffull || first_pixel + count > 0xffffffffull) return fail(ctx, VR_ERR_ARG, "bad pixel span");
+    return VR_OK;
+}
+
+int vr_composite_pair(vr_ctx *ctx, int width, int height, uint64_t first_pixel, uint64_t count, const float *d_mine,
+                      const float *d_theirs, int axis, int mine_is_low, float *d_out)
+{
+    if (!ctx || !d_mine || !d_theirs || !d_out) return fail(ctx, VR_ERR_ARG, "null argument");
+    if (axis < 0 || axis > 2) return fail(ctx, VR_ERR_ARG, "axis must be 0, 1 or 2");
+    if (!ctx->bricks) return fail(ctx, VR_ERR_STATE, "no volume uploaded");
+    if (int rc = pixel_span(ctx, first_pixel, count)) return rc;
+    if (int rc = bind(ctx)) return rc;
+    vr::FrameParams fp;
+    if (int rc = frame_params(ctx, width, height, fp)) return rc;
+    hipLaunchKernelGGL(vr::k_composite_pair, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, fp, (float)ctx->nx,
+                       (float)ctx->ny, (float)ctx->nz, (uint32_t)first_pixel, (uint32_t)count, d_mine, d_theirs, axis, mine_is_low, d_out);
+    VR_HIP(ctx, hipGetLastError());
+    return VR_OK;
+}
+
+int vr_composite_ordered(vr_ctx *ctx, int width, int height, uint64_t first_pixel, uint64_t count, const float *d_parts,
+                         const int *d_slot_of_box, const int grid[3], float *d_out)
+{
+    if (!ctx || !d_parts || !d_slot_of_box || !grid || !d_out) return fail(ctx, VR_ERR_ARG, "null argument");
+    if (grid[0] < 1 || grid[1] < 1 || grid[2] < 1 || (int64_t)grid[0] * grid[1] * grid[2] > 4096) return fail(ctx, VR_ERR_ARG, "bad box grid");
+    if (!ctx->bricks) return fail(ctx, VR_ERR_STATE, "no volume uploaded");
+    if (int rc = pixel_span(ctx, first_pixel, count)) return rc;
+    if (int rc = bind(ctx)) return rc;
+    vr::FrameParams fp;
+    if (int rc = frame_params(ctx, width, height, fp)) return rc;
+    const vr::BoxGrid g{grid[0], grid[1], grid[2]};
+    hipLaunchKernelGGL(vr::k_composite_ordered, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, fp, (float)ctx->nx,
+                       (float)ctx->ny, (float)ctx->nz, (uint32_t)first_pixel, (uint32_t)count, d_parts, d_slot_of_box, g, d_out);
+    VR_HIP(ctx, hipGetLastError());
+    return VR_OK;
+}
+
+int vr_decide_partials(vr_ctx *ctx, int width, int height, uint64_t first_pixel, uint64_t count, const float *d_partials,
+                       uint8_t *d_out_rgba8, uint32_t *d_undecided, uint32_t *d_undecided_count)
+{
+    if (!ctx || !d_partials || !d_out_rgba8 || !d_undecided || !d_undecided_count) return fail(ctx, VR_ERR_ARG, "null argument");
+    if (!ctx->bricks) return fail(ctx, VR_ERR_STATE, "no volume uploaded");
+    if (int rc = pixel_span(ctx, first_pixel, count)) return rc;
+    if (int rc = bind(ctx)) return rc;
+    vr::FrameParams fp;
+    if (int rc = frame_params(ctx, width, height, fp)) return rc;
+    if (int rc = refresh_occupancy(ctx)) return rc;   // brings the table's colour range and rounding bound up to date
+    VR_HIP(ctx, hipMemsetAsync(d_undecided_count, 0, sizeof(uint32_t), ctx->stream));
+    hipLaunchKernelGGL(vr::k_decide_partials, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, fp, ctx->lut_info,
+                       (uint32_t)first_pixel, (uint32_t)count, d_partials, reinterpret_cast<uint32_t *>(d_out_rgba8), d_undecided,
+                       d_undecided_count);
+    VR_HIP(ctx, hipGetLastError());
+    return VR_OK;
+}
+
+int vr_chain_stage(vr_ctx *ctx, int width, int height, const uint32_t *d_pixels, uint64_t count, const float *d_colour_in,
+                   float *d_colour_out, int stage, const int grid[3], const int box[3])
+{
+    if (!ctx || !d_pixels || !d_colour_in || !d_colour_out || !grid || !box) return fail(ctx, VR_ERR_ARG, "null argument");
+    if (grid[0] < 1 || grid[1] < 1 || grid[2] < 1 || (int64_t)grid[0] * grid[1] * grid[2] > 4096) return fail(ctx, VR_ERR_ARG, "bad box grid");
+    for (int k = 0; k < 3; k++)
+        if (box[k] < 0 || box[k] >= grid[k]) return fail(ctx, VR_ERR_ARG, "box outside the grid");
+    if (stage < 0 || stage >= grid[0] * grid[1] * grid[2]) return fail(ctx, VR_ERR_ARG, "stage outside the grid");
+    if (!ctx->bricks) return fail(ctx, VR_ERR_STATE, "no volume uploaded");
+    if (int rc = pixel_span(ctx, 0, count)) return rc;
+    if (int rc = bind(ctx)) return rc;
+    vr::FrameParams fp;
+    if (int rc = frame_params(ctx, width, height, fp)) return rc;
+    if (int rc = refresh_occupancy(ctx)) return rc;
+    const vr::VolumeView vol = view_of(ctx);
+    const float4 border = make_float4(ctx->border[0], ctx->border[1], ctx->border[2], ctx->border[3]);
+    const float4 *lut = reinterpret_cast<const float4 *>(ctx->lut);
+    const vr::BoxGrid g{grid[0], grid[1], grid[2]};
+    const unsigned blocks = (unsigned)std::min<uint64_t>((count + 3) / 4, 2048);
+    if (ctx->dtype == VR_DTYPE_U8)
+        hipLaunchKernelGGL((vr::k_chain_exact<uint8_t>), dim3(blocks), dim3(256), 0, ctx->stream, vol, fp, lut, border, d_pixels, (uint32_t)count,
+                           reinterpret_cast<const float4 *>(d_colour_in), reinterpret_cast<float4 *>(d_colour_out), stage, g, box[0], box[1], box[2]);
+    else
+        hipLaunchKernelGGL((vr::k_chain_exact<uint16_t>), dim3(blocks), dim3(256), 0, ctx->stream, vol, fp, lut, border, d_pixels, (uint32_t)count,
+                           reinterpret_cast<const float4 *>(d_colour_in), reinterpret_cast<float4 *>(d_colour_out), stage, g, box[0], box[1], box[2]);
+    VR_HIP(ctx, hipGetLastError());
+    return VR_OK;
+}
+
+int vr_store_chain(vr_ctx *ctx, const uint32_t *d_pixels, const float *d_colour, uint64_t count, uint64_t first_pixel,
+                   uint64_t pixel_count, uint8_t *d_out_rgba8)
+{
+    if (!ctx || !d_pixels || !d_colour || !d_out_rgba8) return fail(ctx, VR_ERR_ARG, "null argument");
+    if (int rc = pixel_span(ctx, 0, count)) return rc;
+    if (int rc = pixel_span(ctx, first_pixel, pixel_count)) return rc;
+    if (int rc = bind(ctx)) return rc;
+    hipLaunchKernelGGL(vr::k_store_chain, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, d_pixels,
+                       reinterpret_cast<const float4 *>(d_colour), (uint32_t)count, (uint32_t)first_pixel, (uint32_t)pixel_count,
+                       reinterpret_cast<uint32_t *>(d_out_rgba8));
     VR_HIP(ctx, hipGetLastError());
     return VR_OK;
 }

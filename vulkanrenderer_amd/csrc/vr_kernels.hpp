@@ -44,6 +44,11 @@ struct VolumeView {
     // Below the bricks: per brick one bit per 2^3-cell block (4 x 4 x 4 of them, bit z*16 + y*4 + x),
     // set when every tap whose low corner lies in the block gets alpha exactly 0.
     const unsigned long long *micro;
+    // Sub-volume of a sort-last split: the bricks held are those of a box of the whole volume's
+    // brick grid and (ox, oy, oz) is the padded coordinate of the box's first cell (a multiple of
+    // 8).  nbx.., lx.., occ, skip and micro then describe the box, nx.., fx.. still the whole
+    // volume.  All zero when the context holds the whole volume.
+    int ox, oy, oz;
 };
 constexpr int kLevels = 4;
 
@@ -340,10 +345,18 @@ __global__ __launch_bounds__(256) void k_swap_max(T *__restrict__ raw, size_t co
 
 // Re-tiles the linear volume (x fastest, then y, then slice: main.cpp:41,131-146) into bricks and
 // builds the (min,max) macrocell of each brick.  One block per brick.
+// The bricks built are the nbx x nby x (brick_count / (nbx*nby)) box of the volume's brick grid
+// that starts at brick `b0`; `raw` holds the voxels [v0, v0 + (rx, ry, ..)) of the nx x ny x nz
+// volume, which must cover every voxel of the volume those bricks store.
+struct BrickSource {
+    int b0[3];   // first brick of the box
+    int v0[3];   // first voxel held by raw
+    int rx, ry;  // row and column count of raw
+};
 template <typename T>
 __global__ __launch_bounds__(256) void k_build_bricks(const T *__restrict__ raw, T *__restrict__ bricks,
                                                      uint32_t *__restrict__ cells, int nx, int ny, int nz,
-                                                     int nbx, int nby, uint32_t brick_count)
+                                                     int nbx, int nby, uint32_t brick_count, BrickSource src)
 {
     __shared__ uint32_t s_mn[4], s_mx[4];
     // a launch holds at most 2^32 - 1 threads, fewer than a 2048^3 volume has bricks x 256
@@ -355,9 +368,10 @@ __global__ __launch_bounds__(256) void k_build_bricks(const T *__restrict__ raw,
         uint32_t v = 0;
         if (e < kRow * kRow * kRow) {
             const int lx = e % kRow, ly = (e / kRow) % kRow, lz = e / kSlice;
-            const int ix = bx * kBrick + lx - kPad, iy = by * kBrick + ly - kPad, iz = bz * kBrick + lz - kPad;
+            const int ix = (bx + src.b0[0]) * kBrick + lx - kPad, iy = (by + src.b0[1]) * kBrick + ly - kPad,
+                      iz = (bz + src.b0[2]) * kBrick + lz - kPad;
             if ((unsigned)ix < (unsigned)nx && (unsigned)iy < (unsigned)ny && (unsigned)iz < (unsigned)nz)
-                v = raw[((size_t)iz * ny + iy) * nx + ix];
+                v = raw[((size_t)(iz - src.v0[2]) * src.ry + (iy - src.v0[1])) * src.rx + (ix - src.v0[0])];
             mn = v < mn ? v : mn;
             mx = v > mx ? v : mx;
         }
@@ -420,14 +434,20 @@ __device__ __forceinline__ uint32_t phantom_hash(uint32_t seed, uint64_t idx)
     return x >> 8;
 }
 
+// Writes the voxels [lo, lo + ext) of the n^3 phantom, x fastest.
+struct PhantomBox {
+    uint32_t lo[3], ext[3];
+};
 template <typename T>
-__global__ __launch_bounds__(256) void k_phantom(T *__restrict__ out, uint32_t n, uint32_t dmax, uint32_t seed)
+__global__ __launch_bounds__(256) void k_phantom(T *__restrict__ out, uint32_t n, uint32_t dmax, uint32_t seed, PhantomBox box)
 {
-    const uint64_t count = (uint64_t)n * n * n;
+    const uint64_t count = (uint64_t)box.ext[0] * box.ext[1] * box.ext[2];
     const float fn = (float)n;
     const uint32_t range = (dmax + 1) / 128;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t ix = (uint32_t)(i % n), iy = (uint32_t)((i / n) % n), iz = (uint32_t)(i / ((uint64_t)n * n));
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t ix = box.lo[0] + (uint32_t)(j % box.ext[0]), iy = box.lo[1] + (uint32_t)((j / box.ext[0]) % box.ext[1]),
+                       iz = box.lo[2] + (uint32_t)(j / ((uint64_t)box.ext[0] * box.ext[1]));
+        const uint64_t i = ((uint64_t)iz * n + iy) * n + ix;   // index in the whole phantom: seeds the noise
         const float x = (float)(2 * ix + 1) / fn - 1.0f;
         const float y = (float)(2 * iy + 1) / fn - 1.0f;
         const float z = (float)(2 * iz + 1) / fn - 1.0f;
@@ -450,7 +470,7 @@ __global__ __launch_bounds__(256) void k_phantom(T *__restrict__ out, uint32_t n
             tenths = tenths < 0 ? 0 : (tenths > 10 ? 10 : tenths);
             v = (uint32_t)tenths * (dmax - (range - 1)) / 10 + phantom_hash(seed, i) % range;
         }
-        out[i] = (T)v;
+        out[j] = (T)v;
     }
 }
 

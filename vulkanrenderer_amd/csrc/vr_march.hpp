@@ -226,9 +226,10 @@ __device__ __forceinline__ RayModel ray_model(const Ray &r, const VolumeView &v,
     RayModel m;
     // world(t) = o + (tmax - t*step)*d; u = x + .5, v = y + .5, w = -z inside the box
     // (VolumeRendering.comp:168,187)
-    m.ax = (r.o[0] + r.tmax * r.d[0] + 0.5f) * v.fx - 0.5f + (float)kPad;
-    m.ay = (r.o[1] + r.tmax * r.d[1] + 0.5f) * v.fy - 0.5f + (float)kPad;
-    m.az = -(r.o[2] + r.tmax * r.d[2]) * v.fz - 0.5f + (float)kPad;
+    // (for a sub-volume: measured from the first cell of its brick box)
+    m.ax = (r.o[0] + r.tmax * r.d[0] + 0.5f) * v.fx - 0.5f + (float)(kPad - v.ox);
+    m.ay = (r.o[1] + r.tmax * r.d[1] + 0.5f) * v.fy - 0.5f + (float)(kPad - v.oy);
+    m.az = -(r.o[2] + r.tmax * r.d[2]) * v.fz - 0.5f + (float)(kPad - v.oz);
     m.bx = -(step * r.d[0]) * v.fx;
     m.by = -(step * r.d[1]) * v.fy;
     m.bz = (step * r.d[2]) * v.fz;
