@@ -592,7 +592,7 @@ void vro_render_partial(const float *volume, uint32_t nx, uint32_t ny, uint32_t 
                         const int brick_lo[3], const int brick_hi[3], float *out, int threads)
 {
     const sampler_state s = make_sampler(volume, nx, ny, nz, lut, tf_border);
-    const double cut = 0x1p-40;
+    const double cut = 0x1p-20;
 #ifdef _OPENMP
     if (threads <= 0) threads = omp_get_max_threads();
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads)

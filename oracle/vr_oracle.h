@@ -95,7 +95,7 @@ void vro_phantom(void *out, uint32_t n, int dtype_bytes, uint32_t seed);
 
 /* Per pixel five floats (F0, F1, F2, Tr, S): the box's taps taken front to back, F = sum of
  * T a c (double accumulation), Tr = product of (1 - a), S = sum of T over taps with a != 0; the
- * owner of tap 0 adds Tr * c0 and sets Tr = 0; marching stops below Tr = 2^-40; all zero for a
+ * owner of tap 0 adds Tr * c0 and sets Tr = 0; marching stops below Tr = 2^-20; all zero for a
  * ray that misses the volume. */
 void vro_render_partial(const float *volume, uint32_t nx, uint32_t ny, uint32_t nz,
                         const float *lut, const float tf_border[4],

@@ -137,7 +137,7 @@ def test_boxes_assemble_the_single_context_frame(vr, torch, oracle, dtype, n, gr
                 lo, hi = sl.brick_box(bricks, grid, sl.box_of_rank(r, grid))
                 ref = oracle.render_partial(vol, lut, vp[4:8], m, w, h, 90, lo, hi)
                 assert np.allclose(parts[r], ref, rtol=2e-6, atol=1e-7), (cname, r, np.abs(parts[r] - ref).max())
-            assert np.all(merged[:, 3] <= 1e-9)          # every hit ray reached its back tap's owner
+            assert np.all(merged[:, 3] <= 2.0 ** -20)    # every hit ray reached its back tap's owner or went dark
     finally:
         for c in ctxs:
             c.close()
@@ -264,6 +264,32 @@ def test_processes_sharing_one_gpu(vr, torch, oracle, tmp_path, world, schedule,
     got = np.load(path)
     want = whole_frame(vr, oracle.phantom(n, np.uint16), cam, w, h, samples)
     assert want[..., :3].any()
+    assert np.array_equal(got, want), cf.frame_report(got, want)
+
+
+@pytest.mark.parametrize("schedule", ["direct_send", "binary_swap"])
+def test_single_rank_over_rccl(vr, torch, oracle, schedule):
+    """The driver with device tensors in RCCL collectives (one rank: every collective is issued, on the
+    context's stream, and degenerates to a copy)."""
+    import torch.distributed as dist
+    from vulkanrenderer_amd import sortlast as sl
+    n, w, h, samples = 48, 80, 60, 100
+    cam = cf.CAMERAS["h30_v20"]
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1)
+    try:
+        with vr.VolumeRenderer(0) as c:
+            sl.upload_phantom_box(c, n, 2, (1, 1, 1), (0, 0, 0), "cuda")
+            c.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+            c.set_sampling(samples)
+            c.set_camera(*cam)
+            frame = sl.SortLastFrame(sl.HipEngine(c, w, h), w, h, 0, 1, "cuda", schedule=schedule)
+            assert not frame.solo
+            got = frame.render()
+            c.synchronize()
+            got = got.cpu().numpy()
+    finally:
+        dist.destroy_process_group()
+    want = whole_frame(vr, oracle.phantom(n, np.uint16), cam, w, h, samples)
     assert np.array_equal(got, want), cf.frame_report(got, want)
 
 

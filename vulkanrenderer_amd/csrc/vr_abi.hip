@@ -59,6 +59,10 @@ struct vr_ctx {
     float raw_m[16] = {0};
 
     int waves_per_block = 1;
+    // Fetch rounds of the sort-last lane march before a wave takes a ray over.  Boxes cannot stop a ray
+    // as early as the whole-volume march (they do not know what lies in front), so most rays need
+    // several hundred taps and only extreme ones are worth a wave of their own.
+    int partial_budget = 4096;
     int samples = 200;  // VolumeRendering.comp:173
     int mode = VR_MODE_REFERENCE_ORDER;
 
@@ -364,6 +368,7 @@ int vr_create(int device, vr_ctx **out)
         vr_destroy(ctx);
         return VR_ERR_HIP;
     }
+    if (const char *e = std::getenv("VR_PARTIAL_BUDGET")) ctx->partial_budget = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("VR_WAVES_PER_BLOCK")) ctx->waves_per_block = std::max(1, std::min(4, std::atoi(e)));
     ctx->ring_a.resize(vr_ctx::kRing, nullptr);
     ctx->ring_b.resize(vr_ctx::kRing, nullptr);
@@ -897,15 +902,30 @@ int vr_render_partial(vr_ctx *ctx, int width, int height, float *out, int out_is
         }
         d_out = ctx->partial;
     }
+    if (pixels > ctx->queue_cap) {
+        if (ctx->queue) (void)hipFree(ctx->queue);
+        if (ctx->long_queue) (void)hipFree(ctx->long_queue);
+        ctx->queue = nullptr;
+        ctx->long_queue = nullptr;
+        ctx->queue_cap = 0;
+        VR_HIP(ctx, hipMalloc(&ctx->queue, pixels * sizeof(uint32_t)));
+        VR_HIP(ctx, hipMalloc(&ctx->long_queue, pixels * sizeof(vr::LongRay)));
+        ctx->queue_cap = pixels;
+    }
     if (int rc = refresh_occupancy(ctx)) return rc;
+    VR_HIP(ctx, hipMemsetAsync(ctx->counters, 0, offsetof(vr::Counters, lut_error), ctx->stream));
     const int tiles = ((width + 7) / 8) * 2 * ((height + 15) / 16);
     const vr::VolumeView vol = view_of(ctx);
     const float4 border = make_float4(ctx->border[0], ctx->border[1], ctx->border[2], ctx->border[3]);
     const float4 *lut = reinterpret_cast<const float4 *>(ctx->lut);
-    if (ctx->dtype == VR_DTYPE_U8)
-        hipLaunchKernelGGL((vr::k_march_partial<uint8_t>), dim3((unsigned)tiles), dim3(64), 0, ctx->stream, vol, fp, lut, border, d_out);
-    else
-        hipLaunchKernelGGL((vr::k_march_partial<uint16_t>), dim3((unsigned)tiles), dim3(64), 0, ctx->stream, vol, fp, lut, border, d_out);
+    const dim3 long_grid(2048);
+    if (ctx->dtype == VR_DTYPE_U8) {
+        hipLaunchKernelGGL((vr::k_march_partial<uint8_t>), dim3((unsigned)tiles), dim3(64), 0, ctx->stream, vol, fp, lut, border, d_out, ctx->counters, ctx->long_queue, ctx->partial_budget);
+        hipLaunchKernelGGL((vr::k_partial_long<uint8_t>), long_grid, dim3(256), 0, ctx->stream, vol, fp, lut, border, d_out, ctx->counters, ctx->long_queue);
+    } else {
+        hipLaunchKernelGGL((vr::k_march_partial<uint16_t>), dim3((unsigned)tiles), dim3(64), 0, ctx->stream, vol, fp, lut, border, d_out, ctx->counters, ctx->long_queue, ctx->partial_budget);
+        hipLaunchKernelGGL((vr::k_partial_long<uint16_t>), long_grid, dim3(256), 0, ctx->stream, vol, fp, lut, border, d_out, ctx->counters, ctx->long_queue);
+    }
     VR_HIP(ctx, hipGetLastError());
     if (!out_is_device) {
         VR_HIP(ctx, hipMemcpyAsync(out, d_out, pixels * vr::kPartial * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));

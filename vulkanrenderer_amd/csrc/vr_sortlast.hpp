@@ -26,7 +26,10 @@
 namespace vr {
 
 constexpr int kPartial = 5;             // floats per pixel of a partial result
-constexpr double kTrCut = 0x1p-40;      // a box stops marching a ray below this transmittance
+// A box stops marching a ray once the transmittance of its own taps is below this: what it leaves
+// out changes the ray's colour by at most 2 * kTrCut * (largest colour), which k_decide_partials
+// adds to its error interval.
+constexpr double kTrCut = 0x1p-20;
 
 // Cell of a tap in the coordinates of this context's brick box; false when another box owns the tap.
 __device__ __forceinline__ bool tap_cell_local(const Tap &p, const VolumeView &v, Cell &c)
@@ -79,11 +82,37 @@ __device__ __forceinline__ float ray_step(const Ray &r, int samples)
 }
 
 // ---- partial march ------------------------------------------------------------------------------
+// Writes a ray's partial result; adds the back-most tap first when the box owns it.
+template <typename T>
+__device__ __forceinline__ void finish_partial(const VolumeView &vol, const Ray &r, float step, const float4 *s_lut,
+                                               double F0, double F1, double F2, double Tr, float S, float *o)
+{
+    if (!(Tr < kTrCut)) {
+        // back-most tap, if it is this box's: its colour enters unweighted (VolumeRendering.comp:189-191)
+        const Tap p = tap_position(r, vol, step, 0);
+        Cell c;
+        if (tap_cell_local(p, vol, c)) {
+            const float4 tf = sample_tf(s_lut, sample_volume<T>(c, brick_of(c, vol), vol));
+            F0 = __builtin_fma(Tr, (double)tf.x, F0);
+            F1 = __builtin_fma(Tr, (double)tf.y, F1);
+            F2 = __builtin_fma(Tr, (double)tf.z, F2);
+            Tr = 0.0;
+        }
+    }
+    o[0] = (float)F0;
+    o[1] = (float)F1;
+    o[2] = (float)F2;
+    o[3] = (float)Tr;
+    o[4] = S;
+}
+
 // One lane per ray, front to back over the taps this context owns, stepping over empty space like
-// k_march_fast.  out: kPartial floats per pixel of the rectangle.
+// k_march_fast.  out: kPartial floats per pixel of the rectangle.  A lane that has fetched `budget`
+// taps with more to go hands its ray to k_partial_long.
 template <typename T>
 __global__ __launch_bounds__(256) void k_march_partial(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
-                                                      float4 border, float *__restrict__ out)
+                                                      float4 border, float *__restrict__ out, Counters *ctr,
+                                                      LongRay *__restrict__ long_queue, int budget)
 {
     __shared__ float4 s_lut[kLutLds];
     stage_lut(s_lut, lut, border);
@@ -102,7 +131,7 @@ __global__ __launch_bounds__(256) void k_march_partial(VolumeView vol, FramePara
     uint32_t solid = 0xffffffffu;
     unsigned long long solid_mask = 0;
     bool in_air = true;
-    for (;;) {
+    for (int round = 0; round < budget; round++) {
         bool have = false;
         Cell c;
         uint32_t brick = 0;
@@ -163,23 +192,81 @@ __global__ __launch_bounds__(256) void k_march_partial(VolumeView vol, FramePara
         o[0] = o[1] = o[2] = o[3] = o[4] = 0.0f;
         return;
     }
-    if (!(Tr < kTrCut)) {
-        // back-most tap, if it is this box's: its colour enters unweighted (VolumeRendering.comp:189-191)
-        const Tap p = tap_position(r, vol, step, 0);
-        Cell c;
-        if (tap_cell_local(p, vol, c)) {
-            const float4 tf = sample_tf(s_lut, sample_volume<T>(c, brick_of(c, vol), vol));
-            F0 = __builtin_fma(Tr, (double)tf.x, F0);
-            F1 = __builtin_fma(Tr, (double)tf.y, F1);
-            F2 = __builtin_fma(Tr, (double)tf.z, F2);
-            Tr = 0.0;
+    if (marching) {
+        // out of budget with taps left: a wave continues this ray (k_partial_long)
+        LongRay e;
+        e.pixel_id = pixel_id; e.t = t; e.S = S; e.pad_ = 0.0f;
+        e.F0 = F0; e.F1 = F1; e.F2 = F2; e.Tr = Tr;
+        long_queue[atomicAdd(&ctr->long_count, 1u)] = e;
+        return;
+    }
+    finish_partial<T>(vol, r, step, s_lut, F0, F1, F2, Tr, S, o);
+}
+
+// Continuation of the rays k_march_partial ran out of budget on, one wave per ray, 64 consecutive
+// taps per round, folded front to back in tap order (the accumulation of k_march_partial).
+template <typename T>
+__global__ __launch_bounds__(256) void k_partial_long(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
+                                                     float4 border, float *__restrict__ out, const Counters *ctr,
+                                                     const LongRay *__restrict__ long_queue)
+{
+    __shared__ float4 s_lut[kLutLds];
+    stage_lut(s_lut, lut, border);
+    const int lane = threadIdx.x & 63;
+    const uint32_t waves = gridDim.x * 4u;
+    const uint32_t entries = ctr->long_count;
+    for (uint32_t entry = blockIdx.x * 4u + (threadIdx.x >> 6); entry < entries; entry += waves) {
+        const LongRay e = long_queue[entry];
+        int px, py;
+        pixel_of_index(fp, e.pixel_id, px, py);
+        const Ray r = make_ray(fp, px, py);          // identical in every lane
+        const float step = ray_step(r, fp.samples);
+        const RayModel rm = ray_model(r, vol, step, -1.0f);
+        double F0 = e.F0, F1 = e.F1, F2 = e.F2, Tr = e.Tr;
+        float S = e.S;
+        int t = e.t;
+        if (t > rm.t_first) t = rm.t_first;
+        while (t >= rm.t_stop && !(Tr < kTrCut)) {
+            const int n = empty_span(vol, rm, t);   // wave-uniform
+            if (n > 0) {
+                t -= n;
+                continue;
+            }
+            const int tt = t - lane;
+            bool fetch = tt >= rm.t_stop;
+            Cell c;
+            uint32_t brick = 0;
+            if (fetch) {
+                const Tap p = tap_position(r, vol, step, tt);
+                fetch = tap_cell_local(p, vol, c);
+                if (fetch) {
+                    brick = brick_of(c, vol);
+                    if (brick_empty(brick, vol) || micro_empty(vol.micro[brick], c)) fetch = false;
+                }
+            }
+            float4 tf = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (fetch) tf = sample_tf(s_lut, sample_volume<T>(c, brick, vol));
+            unsigned long long todo = __ballot(fetch && tf.w != 0.0f);
+            while (todo && !(Tr < kTrCut)) {
+                const int src = __builtin_ctzll(todo);   // lowest lane = front-most tap of the chunk
+                todo &= todo - 1;
+                const double a = (double)__shfl(tf.w, src);
+                const double w = Tr * a;
+                F0 = __builtin_fma(w, (double)__shfl(tf.x, src), F0);
+                F1 = __builtin_fma(w, (double)__shfl(tf.y, src), F1);
+                F2 = __builtin_fma(w, (double)__shfl(tf.z, src), F2);
+                S += (float)Tr;
+                Tr = Tr * (1.0 - a);
+            }
+            t -= 64;
+        }
+        float res[kPartial];
+        finish_partial<T>(vol, r, step, s_lut, F0, F1, F2, Tr, S, res);
+        if (lane == 0) {
+            float *o = out + (size_t)e.pixel_id * kPartial;
+            for (int k = 0; k < kPartial; k++) o[k] = res[k];
         }
     }
-    o[0] = (float)F0;
-    o[1] = (float)F1;
-    o[2] = (float)F2;
-    o[3] = (float)Tr;
-    o[4] = S;
 }
 
 // ---- combining partial results --------------------------------------------------------------------
@@ -263,7 +350,9 @@ __global__ __launch_bounds__(256) void k_composite_ordered(FrameParams fp, float
 
 // Final bytes of the pixels [first, first + count) from their combined partials.  The interval
 // argument of k_march_fast with two more terms: the floats the partials travelled in (at most 16
-// roundings of values bounded by the largest colour) and the light a box dropped below kTrCut.
+// roundings of values bounded by the largest colour) and the light the boxes dropped below kTrCut
+// (the first box of a ray to stop early leaves out at most 2 * kTrCut * colour; every box behind it
+// is attenuated by that box's transmittance again).
 // Pixels the interval cannot decide are appended to `list` (frame pixel indices).
 __global__ __launch_bounds__(256) void k_decide_partials(FrameParams fp, const LutInfo *__restrict__ info, uint32_t first,
                                                         uint32_t count, const float *__restrict__ partials,
@@ -275,13 +364,13 @@ __global__ __launch_bounds__(256) void k_decide_partials(FrameParams fp, const L
     const float *p = partials + (size_t)i * kPartial;
     const double tr = (double)p[3];
     const float taps = (float)(fp.samples + 2);
-    const float spread = p[4] * 1.001f + ((float)tr + 0x1p-30f) * taps;
+    const float spread = p[4] * 1.001f + ((float)tr + 2.0f * (float)kTrCut) * taps;
     uint32_t bytes = 0xff000000u;
     bool same = info->fast_ok != 0;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         const double mag = fmax(fabs((double)info->cmin[c]), fabs((double)info->cmax[c]));
-        const double e = (double)info->kappa[c] * (double)spread + 16.0 * (double)kUlpHalf * mag;
+        const double e = (double)info->kappa[c] * (double)spread + (16.0 * (double)kUlpHalf + 2.5 * kTrCut) * mag;
         double lo = (double)p[c] + tr * (double)info->cmin[c] - e;
         double hi = (double)p[c] + tr * (double)info->cmax[c] + e;
         lo -= fabs(lo) * 1e-7 + 1e-38;

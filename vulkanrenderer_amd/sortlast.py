@@ -140,6 +140,8 @@ class SortLastFrame:
         self.grid = tuple(grid) if grid is not None else box_grid(world)
         assert self.grid[0] * self.grid[1] * self.grid[2] == world
         self.box = box_of_rank(rank, self.grid)
+        # a single rank outside any process group needs no collectives; inside one it still issues them
+        self.solo = world == 1 and not dist.is_initialized()
         self.pixels = width * height
         unit = world * 64
         self.padded = (self.pixels + unit - 1) // unit * unit
@@ -200,7 +202,7 @@ class SortLastFrame:
 
     # -- step 2 -------------------------------------------------------------------------------------
     def _merge_direct_send(self):
-        if self.world == 1:
+        if self.solo:
             self.e.composite_ordered(0, self.span, self.partial, self.slot_of_box, self.grid, self.merged)
             return
         parts = self._all_to_all(self.partial)          # [world, span, 5]: slot s = rank s's partials of my span
@@ -239,7 +241,7 @@ class SortLastFrame:
             return self._gather()
 
     def _remarch(self):
-        if self.world == 1:
+        if self.solo:
             counts = self.undecided_count.view(1, 1)
             lists = self.undecided.view(1, -1)
         else:
@@ -248,7 +250,7 @@ class SortLastFrame:
         self.remarched = sum(counts)
         if self.remarched == 0:
             return
-        if self.world > 1:
+        if not self.solo:
             longest = max(counts)
             lists = self._all_gather(self.undecided[:longest])
         pixels = torch.cat([lists[r, : counts[r]] for r in range(self.world)]).contiguous()
@@ -256,13 +258,13 @@ class SortLastFrame:
         nxt = torch.empty_like(colour)
         for stage in range(self.world):
             self.e.chain_stage(pixels, colour, nxt, stage, self.grid, self.box)
-            if self.world > 1:
+            if not self.solo:
                 self._all_reduce_sum(nxt)
             colour, nxt = nxt, colour
         self.e.store_chain(pixels, colour, self.first, self.span, self.bytes)
 
     def _gather(self):
-        if self.world == 1:
+        if self.solo:
             self.frame[: self.span].copy_(self.bytes)
         else:
             s = self._host(self.bytes)
