@@ -26,7 +26,7 @@ ctx.set_sampling(bench.samples_for(n))
 ctx.set_mode(1)
 out = torch.empty(w * h * 4, dtype=torch.uint8, device="cuda")
 waves = ((w + 7) // 8) * ((h + 15) // 16) * 2 + 8
-tl = torch.zeros(waves * 4, dtype=torch.int64, device="cuda")
+tl = torch.zeros(waves * 8, dtype=torch.int64, device="cuda")
 torch.cuda.synchronize()
 L = vr.lib()
 L.vr_diag_set_timeline.argtypes = [C.c_void_p, C.c_void_p]
@@ -39,7 +39,7 @@ ctx.set_camera(*bench.orbit_camera(30))
 ctx.render_device(w, h, out.data_ptr())
 ctx.synchronize()
 print("kernel ms", ctx.march_kernel_times(1))
-t = tl.cpu().numpy().reshape(-1, 4)
+t = tl.cpu().numpy().reshape(-1, 8)
 t = t[t[:, 0] != 0]
 t0, t1 = t[:, 0].astype(np.float64), t[:, 1].astype(np.float64)
 base = t0.min()
@@ -75,7 +75,31 @@ print("sum dur (wave-us)", dur.sum(), "-> avg resident waves", dur.sum() / t1.ma
 # the longest waves: where are they in the image
 order = np.argsort(-dur)[:10]
 tiles_x = (w + 7) // 8
-ids = np.nonzero(tl.cpu().numpy().reshape(-1, 4)[:, 0])[0]
+ids = np.nonzero(tl.cpu().numpy().reshape(-1, 8)[:, 0])[0]
 for k in order:
     wid = ids[k]
-    print("wave", wid, "tile", wid % tiles_x, wid // tiles_x, "dur us %.1f start %.0f" % (dur[k], t0[k]))
+    print("wave", wid, "tile", wid % tiles_x, wid // tiles_x, "dur us %.1f start %.0f" % (dur[k], t0[k]),
+          "rounds %d model %d exact %d both %d sampled %d" % (rounds[k], mmodel[k], mexact[k], mboth[k], ssum[k]))
+late = np.argsort(-t1)[:12]
+print("last waves to finish:")
+for k in late:
+    wid = ids[k]
+    print("wave", wid, "tile", wid % tiles_x, wid // tiles_x, "dur us %.1f start %.0f end %.0f" % (dur[k], t0[k], t1[k]),
+          "rounds %d model %d exact %d both %d sampled %d" % (rounds[k], mmodel[k], mexact[k], mboth[k], ssum[k]))
+for lo, hi in ((0, 50), (50, 100), (100, 200), (200, 400), (400, 800), (800, 1e9)):
+    sel = (dur >= lo) & (dur < hi)
+    print("dur %4.0f..%-6.0f us: %6d waves, %.3f of wave-time, mean rounds %.1f both %.1f" % (
+        lo, hi, sel.sum(), dur[sel].sum() / dur.sum(), rounds[sel].mean() if sel.any() else 0, mboth[sel].mean() if sel.any() else 0))
+
+
+# cycles by phase (shader clock, elapsed while the wave shares its SIMD with others)
+cyc = t[:, 4:8].astype(np.float64)
+tot = cyc[:, 3].sum()
+print("cycle share: setup %.3f skip-loop %.3f sample %.3f rest %.3f" % (
+    cyc[:, 0].sum() / tot, cyc[:, 1].sum() / tot, cyc[:, 2].sum() / tot, 1 - cyc[:, :3].sum() / tot))
+b = busy
+totb = cyc[b, 3].sum()
+print("busy waves (%.2f of all cycles): setup %.3f skip-loop %.3f sample %.3f; per round skip %.0f sample %.0f cycles" % (
+    totb / tot, cyc[b, 0].sum() / totb, cyc[b, 1].sum() / totb, cyc[b, 2].sum() / totb,
+    cyc[b, 1].sum() / rounds[b].sum(), cyc[b, 2].sum() / rounds[b].sum()))
+print("idle waves: setup %.0f skip-loop %.0f total %.0f cycles per wave" % (cyc[~b, 0].mean(), cyc[~b, 1].mean(), cyc[~b, 3].mean()))

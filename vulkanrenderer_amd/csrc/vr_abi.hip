@@ -59,6 +59,9 @@ struct vr_ctx {
     float raw_m[16] = {0};
 
     int waves_per_block = 1;
+    // memory round trips (fetch rounds + passes of the skipping loop) a lane spends on a ray before a
+    // wave takes the ray over
+    int lane_budget = vr::kLaneBudget;
     // Fetch rounds of the sort-last lane march before a wave takes a ray over.  Boxes cannot stop a ray
     // as early as the whole-volume march (they do not know what lies in front), so most rays need
     // several hundred taps and only extreme ones are worth a wave of their own.
@@ -328,15 +331,15 @@ void launch_frame(vr_ctx *ctx, const vr::FrameParams &fp, uint32_t *d_out, bool 
             hipLaunchKernelGGL((vr::k_march_exact<T, true, false>), grid, block, 0, s, vol, fp, lut, border, d_out, ctx->counters, ctx->touched);
         (void)hipEventRecord(ctx->ring_b[slot], s);
     } else {
-        // front-to-back march, then the rays it could not decide in reference order
+        // front-to-back march, then the rays it could not finish or decide, one wave per ray
         const dim3 replay_grid(2048);  // 8192 waves, one ray each per pass
         if (stats) {
-            hipLaunchKernelGGL((vr::k_march_fast<T, true>), grid, block, 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue, ctx->long_queue);
+            hipLaunchKernelGGL((vr::k_march_fast<T, true>), grid, block, 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue, ctx->long_queue, ctx->lane_budget);
             (void)hipEventRecord(ctx->ring_b[slot], s);
             hipLaunchKernelGGL((vr::k_march_long<T, true>), replay_grid, dim3(256), 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue, ctx->long_queue);
             hipLaunchKernelGGL((vr::k_replay_exact<T, true>), replay_grid, dim3(256), 0, s, vol, fp, lut, border, d_out, ctx->counters, ctx->touched, ctx->queue);
         } else {
-            hipLaunchKernelGGL((vr::k_march_fast<T, false>), grid, block, 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue, ctx->long_queue);
+            hipLaunchKernelGGL((vr::k_march_fast<T, false>), grid, block, 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue, ctx->long_queue, ctx->lane_budget);
             (void)hipEventRecord(ctx->ring_b[slot], s);
             hipLaunchKernelGGL((vr::k_march_long<T, false>), replay_grid, dim3(256), 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue, ctx->long_queue);
             hipLaunchKernelGGL((vr::k_replay_exact<T, false>), replay_grid, dim3(256), 0, s, vol, fp, lut, border, d_out, ctx->counters, ctx->touched, ctx->queue);
@@ -368,6 +371,7 @@ int vr_create(int device, vr_ctx **out)
         vr_destroy(ctx);
         return VR_ERR_HIP;
     }
+    if (const char *e = std::getenv("VR_LANE_BUDGET")) ctx->lane_budget = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("VR_PARTIAL_BUDGET")) ctx->partial_budget = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("VR_WAVES_PER_BLOCK")) ctx->waves_per_block = std::max(1, std::min(4, std::atoi(e)));
     ctx->ring_a.resize(vr_ctx::kRing, nullptr);

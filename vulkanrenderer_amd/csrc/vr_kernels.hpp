@@ -96,20 +96,28 @@ struct Voxel;
 template <>
 struct Voxel<uint16_t> {
     // two neighbouring voxels of a brick row with one (possibly unaligned) 4-byte load
-    static __device__ __forceinline__ void pair(const uint16_t *p, float &a, float &b)
+    static __device__ __forceinline__ uint32_t load_pair(const uint16_t *p)
     {
         uint32_t w;
         __builtin_memcpy(&w, p, 4);
+        return w;
+    }
+    static __device__ __forceinline__ void split(uint32_t w, float &a, float &b)
+    {
         a = (float)(w & 0xffffu);
         b = (float)(w >> 16);
     }
 };
 template <>
 struct Voxel<uint8_t> {
-    static __device__ __forceinline__ void pair(const uint8_t *p, float &a, float &b)
+    static __device__ __forceinline__ uint32_t load_pair(const uint8_t *p)
     {
         uint16_t w;
         __builtin_memcpy(&w, p, 2);
+        return w;
+    }
+    static __device__ __forceinline__ void split(uint32_t w, float &a, float &b)
+    {
         a = (float)(w & 0xffu);
         b = (float)(w >> 8);
     }
@@ -194,17 +202,32 @@ __device__ __forceinline__ uint32_t brick_of(const Cell &c, const VolumeView &v)
 }
 
 // texture(volumeTexture, tc).x with linear filtering and clamp-to-border (border .r = 0):
-// VolumeRendering.comp:187-188, sampler main.cpp:365-382.
+// VolumeRendering.comp:187-188, sampler main.cpp:365-382.  In two halves so that a lane can have
+// the loads of several taps in flight before it filters the first: the eight corners of a tap as
+// four pairs of x-neighbours, then the arithmetic.
+struct TapWords {
+    uint32_t w[4];   // pairs (x, x+1) at (y, z), (y+1, z), (y, z+1), (y+1, z+1)
+};
 template <typename T>
-__device__ __forceinline__ float sample_volume(const Cell &c, uint32_t brick, const VolumeView &v)
+__device__ __forceinline__ TapWords fetch_volume(const Cell &c, uint32_t brick, const VolumeView &v)
 {
     const T *base = (const T *)v.bricks + (size_t)brick * kBrickElems +
                     (((c.sz & 7) * kRow + (c.sy & 7)) * kRow + (c.sx & 7));
+    TapWords r;
+    r.w[0] = Voxel<T>::load_pair(base);
+    r.w[1] = Voxel<T>::load_pair(base + kRow);
+    r.w[2] = Voxel<T>::load_pair(base + kSlice);
+    r.w[3] = Voxel<T>::load_pair(base + kSlice + kRow);
+    return r;
+}
+template <typename T>
+__device__ __forceinline__ float filter_volume(const TapWords &raw, const Cell &c, const VolumeView &v)
+{
     float r000, r100, r010, r110, r001, r101, r011, r111;
-    Voxel<T>::pair(base, r000, r100);
-    Voxel<T>::pair(base + kRow, r010, r110);
-    Voxel<T>::pair(base + kSlice, r001, r101);
-    Voxel<T>::pair(base + kSlice + kRow, r011, r111);
+    Voxel<T>::split(raw.w[0], r000, r100);
+    Voxel<T>::split(raw.w[1], r010, r110);
+    Voxel<T>::split(raw.w[2], r001, r101);
+    Voxel<T>::split(raw.w[3], r011, r111);
     const float hi = v.inv_hi, lo = v.inv_lo;
     const float c000 = __builtin_fmaf(r000, hi, r000 * lo), c100 = __builtin_fmaf(r100, hi, r100 * lo);
     const float c010 = __builtin_fmaf(r010, hi, r010 * lo), c110 = __builtin_fmaf(r110, hi, r110 * lo);
@@ -213,6 +236,11 @@ __device__ __forceinline__ float sample_volume(const Cell &c, uint32_t brick, co
     const float p0 = lerp_fma(c.wy, lerp_fma(c.wx, c000, c100), lerp_fma(c.wx, c010, c110));
     const float p1 = lerp_fma(c.wy, lerp_fma(c.wx, c001, c101), lerp_fma(c.wx, c011, c111));
     return lerp_fma(c.wz, p0, p1);
+}
+template <typename T>
+__device__ __forceinline__ float sample_volume(const Cell &c, uint32_t brick, const VolumeView &v)
+{
+    return filter_volume<T>(fetch_volume<T>(c, brick, v), c, v);
 }
 
 // texture(transferSampler, intensity): VolumeRendering.comp:98-106.

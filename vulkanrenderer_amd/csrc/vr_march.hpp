@@ -468,84 +468,75 @@ __global__ __launch_bounds__(256) void k_march_exact(VolumeView vol, FrameParams
     }
 }
 
-// Reference-order march of the rays listed in `queue` (count in ctr->replay_count), one wave per
-// ray: the fast march hands over the few rays whose bytes it could not decide, far too few to
-// fill the chip with one lane each.  The 64 lanes fetch 64 consecutive taps at once; the blend
-// itself is inherently serial, so the lanes' (alpha, colour) are then folded in tap order with
-// the shader's expression.  Taps with alpha exactly 0 and a finite colour are identities and are
-// left out of the fold; the back-most tap assigns.
+// Reference-order march of one ray by a whole wave: the fast march hands over the few rays whose
+// bytes it could not decide, far too few to fill the chip with one lane each.  The 64 lanes fetch 64
+// consecutive taps at once; the blend itself is inherently serial, so the lanes' (alpha, colour) are
+// then folded in tap order with the shader's expression.  Taps with alpha exactly 0 and a finite
+// colour are identities and are left out of the fold; the back-most tap assigns.
 template <typename T, bool STATS>
-__global__ __launch_bounds__(256) void k_replay_exact(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
-                                                     float4 border, uint32_t *__restrict__ out, Counters *ctr,
-                                                     uint32_t *touched, const uint32_t *__restrict__ queue)
+__device__ __forceinline__ void replay_ray(const VolumeView &vol, const FrameParams &fp, const float4 *s_lut,
+                                           uint32_t *__restrict__ out, Counters *ctr, uint32_t *touched, uint32_t out_index)
 {
-    __shared__ float4 s_lut[kLutLds];
-    stage_lut(s_lut, lut, border);
     const int lane = threadIdx.x & 63;
-    const uint32_t waves = gridDim.x * 4u;
-    const uint32_t entries = ctr->replay_count;
-    for (uint32_t entry = blockIdx.x * 4u + (threadIdx.x >> 6); entry < entries; entry += waves) {
-        const uint32_t out_index = queue[entry];
-        int px, py;
-        pixel_of_index(fp, out_index, px, py);
-        const Ray r = make_ray(fp, px, py);          // identical in every lane
-        const int last = fp.samples + 1;
-        const float step = (r.tmax - r.tmin) / (float)(uint32_t)last;
-        const RayModel rm = ray_model(r, vol, step, 1.0f);
-        float cr = 0.0f, cg = 0.0f, cb = 0.0f;
-        unsigned long long evaluated = 0;
-        int base = 0;
-        while (base <= last) {
-            if (base > 0) {
-                if (base < rm.t_stop) base = rm.t_stop;    // nothing occupied before or beyond these taps
-                if (base > rm.t_first || base > last) break;
-                const int n = empty_span(vol, rm, base);   // wave-uniform: whole runs of empty taps
-                if (n > 0) {
-                    base += n;
-                    continue;
-                }
+    int px, py;
+    pixel_of_index(fp, out_index, px, py);
+    const Ray r = make_ray(fp, px, py);          // identical in every lane
+    const int last = fp.samples + 1;
+    const float step = (r.tmax - r.tmin) / (float)(uint32_t)last;
+    const RayModel rm = ray_model(r, vol, step, 1.0f);
+    float cr = 0.0f, cg = 0.0f, cb = 0.0f;
+    unsigned long long evaluated = 0;
+    int base = 0;
+    while (base <= last) {
+        if (base > 0) {
+            if (base < rm.t_stop) base = rm.t_stop;    // nothing occupied before or beyond these taps
+            if (base > rm.t_first || base > last) break;
+            const int n = empty_span(vol, rm, base);   // wave-uniform: whole runs of empty taps
+            if (n > 0) {
+                base += n;
+                continue;
             }
-            const int t = base + lane;
-            bool fetch = t <= last;
-            Cell c;
-            uint32_t brick = 0;
-            if (fetch) {
-                const Tap p = tap_position(r, vol, step, t);
-                c = tap_cell(p, vol);
-                brick = brick_of(c, vol);
-                if (t > 0 && (brick_empty(brick, vol) || micro_empty(vol.micro[brick], c))) fetch = false;
-            }
-            float4 tf = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (fetch) {
-                tf = sample_tf(s_lut, sample_volume<T>(c, brick, vol));
-                if (STATS) {
-                    evaluated++;
-                    atomicOr(&touched[brick >> 5], 1u << (brick & 31));
-                }
-            }
-            const bool identity = tf.w == 0.0f && isfinite(tf.x) && isfinite(tf.y) && isfinite(tf.z);
-            unsigned long long todo = __ballot(fetch && (t == 0 || !identity));
-            while (todo) {
-                const int src = __builtin_ctzll(todo);
-                todo &= todo - 1;
-                const float a = __shfl(tf.w, src), x = __shfl(tf.x, src), y = __shfl(tf.y, src), z = __shfl(tf.z, src);
-                if (base + src == 0) {
-                    cr = x; cg = y; cb = z;
-                } else {
-                    const float ia = 1.0f - a;
-                    cr = a * x + ia * cr;
-                    cg = a * y + ia * cg;
-                    cb = a * z + ia * cb;
-                }
-            }
-            base += 64;
         }
-        if (!r.hit) { cr = cg = cb = 0.0f; }
-        if (lane == 0) out[out_index] = pack_rgba8(cr, cg, cb);
-        if (STATS) {
-            if (lane == 0) atomicAdd(&ctr->replay_rays, 1ull);
-            atomicAdd(&ctr->samples_evaluated, evaluated);
+        const int t = base + lane;
+        bool fetch = t <= last;
+        Cell c;
+        uint32_t brick = 0;
+        if (fetch) {
+            const Tap p = tap_position(r, vol, step, t);
+            c = tap_cell(p, vol);
+            brick = brick_of(c, vol);
+            if (t > 0 && (brick_empty(brick, vol) || micro_empty(vol.micro[brick], c))) fetch = false;
         }
+        float4 tf = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (fetch) {
+            tf = sample_tf(s_lut, sample_volume<T>(c, brick, vol));
+            if (STATS) {
+                evaluated++;
+                atomicOr(&touched[brick >> 5], 1u << (brick & 31));
+            }
+        }
+        const bool identity = tf.w == 0.0f && isfinite(tf.x) && isfinite(tf.y) && isfinite(tf.z);
+        unsigned long long todo = __ballot(fetch && (t == 0 || !identity));
+        while (todo) {
+            const int src = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const float a = __shfl(tf.w, src), x = __shfl(tf.x, src), y = __shfl(tf.y, src), z = __shfl(tf.z, src);
+            if (base + src == 0) {
+                cr = x; cg = y; cb = z;
+            } else {
+                const float ia = 1.0f - a;
+                cr = a * x + ia * cr;
+                cg = a * y + ia * cg;
+                cb = a * z + ia * cb;
+            }
+        }
+        base += 64;
+    }
+    if (!r.hit) { cr = cg = cb = 0.0f; }
+    if (lane == 0) out[out_index] = pack_rgba8(cr, cg, cb);
+    if (STATS) {
+        if (lane == 0) atomicAdd(&ctr->replay_rays, 1ull);
+        atomicAdd(&ctr->samples_evaluated, evaluated);
     }
 }
 
@@ -601,9 +592,25 @@ struct LongRay {
 // latency-bound chain a single slow ray (one that grazes the object without ever becoming opaque)
 // can keep its wave alive for.
 #ifndef VR_LANE_BUDGET
-#define VR_LANE_BUDGET 64
+#define VR_LANE_BUDGET 160
 #endif
 constexpr int kLaneBudget = VR_LANE_BUDGET;
+#ifndef VR_DECIDE_EVERY
+#define VR_DECIDE_EVERY 4
+#endif
+constexpr int kDecideEvery = VR_DECIDE_EVERY;   // a power of two
+#ifndef VR_MATERIAL_BET
+#define VR_MATERIAL_BET true
+#endif
+constexpr bool kMaterialBet = VR_MATERIAL_BET;
+#ifndef VR_CLEAR_RUN
+#define VR_CLEAR_RUN 3
+#endif
+constexpr int kClearRun = VR_CLEAR_RUN;   // transparent taps in a row that end the bet on material
+#ifndef VR_TAP_GROUP
+#define VR_TAP_GROUP 1
+#endif
+constexpr int kTapGroup = VR_TAP_GROUP;   // taps a lane inside material fetches per round
 
 // ---- front-to-back march ------------------------------------------------------------------------
 // Visits the taps from the eye towards the back, steps over empty cubes of the occupancy pyramid,
@@ -622,24 +629,21 @@ constexpr int kLaneBudget = VR_LANE_BUDGET;
 // the back tap is appended to a queue and re-marched in reference order by k_replay_exact.
 // The loop leaves a wave when no lane has a tap left (wavefront ballot): lanes first step over
 // empty space (cheap, divergent), then all lanes that found a tap fetch it together.
-template <typename T, bool STATS>
-__global__ __launch_bounds__(256, VR_FAST_MIN_WAVES) void k_march_fast(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
-                                                   float4 border, const LutInfo *__restrict__ info,
-                                                   uint32_t *__restrict__ out, Counters *ctr, uint32_t *touched,
-                                                   uint32_t *__restrict__ queue, LongRay *__restrict__ long_queue)
+//
+// One lane marches one ray; the 64 rays of a wave are the pixels of an 8x8 tile.
+template <typename T, bool STATS, bool RESUME>
+__device__ __forceinline__ void march_lanes(const VolumeView &vol, const FrameParams &fp, const float4 *s_lut,
+                                            const Decider &dec, uint32_t *__restrict__ out, Counters *ctr,
+                                            uint32_t *touched, uint32_t *__restrict__ queue,
+                                            LongRay *__restrict__ next_queue, unsigned int *next_count, int budget,
+                                            bool in_rect, int px, int py, uint32_t pixel_id, const LongRay &resume)
 {
-    __shared__ float4 s_lut[kLutLds];
 #ifdef VR_DIAG
     const unsigned long long diag_t0 = wall_clock64();
     unsigned int diag_model = 0, diag_exact = 0, diag_rounds = 0, diag_sampled = 0;
+    long long diag_c0 = clock64(), diag_setup = 0, diag_skip = 0, diag_sample = 0;
 #endif
-    stage_lut(s_lut, lut, border);
-    int px, py;
-    uint32_t pixel_id;
-    const bool in_rect = lane_pixel(fp, px, py, pixel_id);
-
     const Ray r = make_ray(fp, in_rect ? px : fp.x0, in_rect ? py : fp.y0);
-    const Decider dec(info);
     const bool fast_ok = dec.ok;
 
     const int last = fp.samples + 1;
@@ -649,6 +653,11 @@ __global__ __launch_bounds__(256, VR_FAST_MIN_WAVES) void k_march_fast(VolumeVie
     double F0 = 0.0, F1 = 0.0, F2 = 0.0, Tr = 1.0;
     float S = 0.0f;
     int t = last < rm.t_first ? last : rm.t_first;   // front-most tap that can matter
+    if (RESUME) {
+        F0 = resume.F0; F1 = resume.F1; F2 = resume.F2; Tr = resume.Tr;
+        S = resume.S;
+        t = resume.t < t ? resume.t : t;
+    }
     const int t_stop = rm.t_stop;       // taps below it (the back tap aside) cannot matter either
     bool marching = in_rect && r.hit;   // still has taps with index >= 1 to visit
     bool decided = false;
@@ -659,92 +668,184 @@ __global__ __launch_bounds__(256, VR_FAST_MIN_WAVES) void k_march_fast(VolumeVie
 
     uint32_t solid = 0xffffffffu;       // last brick found occupied: its taps need no pyramid lookup
     unsigned long long solid_mask = 0;  // and its 2^3-cell block bits
-    bool in_air = true;                 // the last tap looked at was in an empty cube
-    for (int round = 0; round < kLaneBudget; round++) {
-        // 1. step over empty space until this lane stands on a tap that must be fetched
+    bool in_air = !RESUME;              // the last tap looked at was in an empty cube: the line model leads
+    // The last tap fetched had alpha != 0 (or only one transparent tap since): the next tap is fetched
+    // without asking the occupancy tables.  Any tap may be fetched, so this is only a bet that saves the
+    // look-ups while a ray is inside material; two transparent taps in a row end it.
+    bool material = false;
+    int clear_run = 0;
+    // Work a lane has spent on its ray: taps fetched plus passes of the skipping loop.  Every pass and
+    // every fetch is a memory round trip the whole wave waits for, so a ray that needs many of them is
+    // handed to a wave of its own (k_march_long) instead of holding 63 other lanes.
+    int work = 0;
+#ifdef VR_DIAG
+    diag_setup = clock64() - diag_c0;
+#endif
+    for (int round = 0;; round++) {
+#ifdef VR_DIAG
+        const long long diag_r0 = clock64();
+#endif
+        // taps this lane fetches this round: tap t in slot 0, and while it is inside material the
+        // kTapGroup - 1 taps behind it as well, so that their loads are in flight together
+        int taps = 0;
+        Cell cs[kTapGroup];
+        uint32_t bricks[kTapGroup];
+        Cell &c = cs[0];
+        uint32_t &brick = bricks[0];
         bool have = false;
-        Cell c;
-        uint32_t brick = 0;
-        while (marching && !have) {
-            if (t < t_stop) { marching = false; break; }
-            if (in_air) {
-                // crossing empty space: walk the line model, no exact positions needed
-#ifdef VR_DIAG
-                diag_model++;
-#endif
-                if (STATS) lookups++;
-                const int n = empty_span(vol, rm, t);
-                if (n > 0) {
-                    t -= n;
-                    continue;
-                }
-            }
-#ifdef VR_DIAG
-            diag_exact++;
-#endif
-            const Tap p = tap_position(r, vol, step, t);
-            c = tap_cell(p, vol);
-            brick = brick_of(c, vol);
-            if (brick != solid) {
-                if (STATS) lookups++;
-                const int level = empty_level(vol, c.sx >> 3, c.sy >> 3, c.sz >> 3);
-                if (level >= 0) {
-                    // tap t is in an empty cube for certain (exact cell); the line model says how
-                    // many of the following taps are too
-                    const int n = empty_span_at(vol, rm, t, level, c.sx >> 3, c.sy >> 3, c.sz >> 3);
-                    t -= n > 1 ? n : 1;
-                    in_air = true;
-                    continue;
-                }
-                solid = brick;
-                solid_mask = vol.micro[brick];
-            }
-            in_air = false;
-            if (micro_empty(solid_mask, c)) {
-                // occupied brick, transparent 2^3-cell block of it: step to the block's far side
-                const int n = block_span(rm, t, c);
-                t -= n > 1 ? n : 1;
+        const bool active = marching && work < budget;
+        if (material && active) {
+            if (t < t_stop) {
+                marching = false;
             } else {
+                taps = t - t_stop + 1 < kTapGroup ? t - t_stop + 1 : kTapGroup;
+#pragma unroll
+                for (int k = 0; k < kTapGroup; k++) {
+                    cs[k] = tap_cell(tap_position(r, vol, step, t - k), vol);   // for k >= taps: a valid cell, never fetched
+                    bricks[k] = brick_of(cs[k], vol);
+                }
                 have = true;
             }
         }
+        // 1. lanes outside material step over empty space until they stand on a tap that must be
+        //    fetched.  One pass of the loop looks at one tap: through the line model while in empty
+        //    space (cheap), through its exact position otherwise; either way the answer is "inside an
+        //    empty cube of the pyramid", "inside a transparent 2^3-cell block" (both: count how many taps
+        //    stay inside and step over them) or "fetch it".
+        while (marching && !have && work < budget) {
+            if (t < t_stop) { marching = false; break; }
+            work++;
+            const float ft = (float)t;
+            const float gx = __builtin_fmaf(ft, rm.bx, rm.ax), gy = __builtin_fmaf(ft, rm.by, rm.ay),
+                        gz = __builtin_fmaf(ft, rm.bz, rm.az);
+            if (in_air) {
+#ifdef VR_DIAG
+                diag_model++;
+#endif
+                c.sx = min((int)fminf(fmaxf(gx, 0.0f), 1e7f), vol.lx[0] * kBrick - 1);
+                c.sy = min((int)fminf(fmaxf(gy, 0.0f), 1e7f), vol.ly[0] * kBrick - 1);
+                c.sz = min((int)fminf(fmaxf(gz, 0.0f), 1e7f), vol.lz[0] * kBrick - 1);
+            } else {
+#ifdef VR_DIAG
+                diag_exact++;
+#endif
+                c = tap_cell(tap_position(r, vol, step, t), vol);
+            }
+            brick = brick_of(c, vol);
+            int level = -1;
+            if (brick != solid) {
+                if (STATS) lookups++;
+                // both tables are read at once (the block bits only matter for an occupied brick found
+                // through an exact position): one memory round trip instead of two in a row
+                const uint32_t code = skip_code(brick, vol);
+                unsigned long long bits = 0;
+                if (!in_air) bits = vol.micro[brick];
+                level = (int)code - 1;
+                if (level < 0) {
+                    if (in_air) {
+                        // the model points into an occupied brick: look again with the exact position
+                        in_air = false;
+                        continue;
+                    }
+                    solid = brick;
+                    solid_mask = bits;
+                }
+            } else if (in_air) {
+                in_air = false;
+                continue;
+            }
+            int lox, loy, loz;
+            float extent;
+            if (level >= 0) {
+                const int shift = 3 + 2 * level;
+                lox = (c.sx >> shift) << shift;
+                loy = (c.sy >> shift) << shift;
+                loz = (c.sz >> shift) << shift;
+                extent = (float)(1 << shift);
+            } else if (micro_empty(solid_mask, c)) {
+                lox = c.sx & ~1;
+                loy = c.sy & ~1;
+                loz = c.sz & ~1;
+                extent = 2.0f;
+            } else {
+                have = true;
+                taps = 1;
+                continue;
+            }
+            const int n = span_inside(gx, gy, gz, lox, loy, loz, extent, rm);
+            if (in_air) {
+                // the cell came from the model: only a model position inside the shrunk cube proves anything
+                if (n > 0) t -= n;
+                else in_air = false;
+            } else {
+                // exact cell: tap t itself is transparent for certain, the model counts the taps after it
+                t -= n > 1 ? n : 1;
+                in_air = level >= 0;
+            }
+        }
         // 2. the wave leaves the loop when no lane has a tap to fetch
+#ifdef VR_DIAG
+        const long long diag_r1 = clock64();
+        diag_skip += diag_r1 - diag_r0;
+#endif
         if (__ballot(have) == 0ull) break;
 #ifdef VR_DIAG
         diag_rounds++;
-        diag_sampled += have ? 1u : 0u;
+        diag_sampled += (unsigned int)taps;
 #endif
         if (have) {
-            const float inten = sample_volume<T>(c, brick, vol);
-            const float4 tf = sample_tf(s_lut, inten);
-            if (STATS) {
-                evaluated++;
-                atomicOr(&touched[brick >> 5], 1u << (brick & 31));
-            }
-            if (tf.w != 0.0f) {
-                const double a = (double)tf.w;
-                const double w = Tr * a;
-                F0 = __builtin_fma(w, (double)tf.x, F0);
-                F1 = __builtin_fma(w, (double)tf.y, F1);
-                F2 = __builtin_fma(w, (double)tf.z, F2);
-                S += (float)Tr;
-                Tr = Tr * (1.0 - a);
-                // early termination: worth testing once little light can still come through
-                if (fast_ok && Tr < 0.03125 && try_decide(t)) {
-                    decided = true;
-                    marching = false;
+            work++;
+            TapWords raw[kTapGroup];
+#pragma unroll
+            for (int k = 0; k < kTapGroup; k++)
+                if (k < taps) raw[k] = fetch_volume<T>(cs[k], bricks[k], vol);
+#pragma unroll
+            for (int k = 0; k < kTapGroup; k++) {
+                if (k >= taps) break;
+                const float4 tf = sample_tf(s_lut, filter_volume<T>(raw[k], cs[k], vol));
+                if (STATS) {
+                    evaluated++;
+                    atomicOr(&touched[bricks[k] >> 5], 1u << (bricks[k] & 31));
+                }
+                if (tf.w != 0.0f) {
+                    const double a = (double)tf.w;
+                    const double w = Tr * a;
+                    F0 = __builtin_fma(w, (double)tf.x, F0);
+                    F1 = __builtin_fma(w, (double)tf.y, F1);
+                    F2 = __builtin_fma(w, (double)tf.z, F2);
+                    S += (float)Tr;
+                    Tr = Tr * (1.0 - a);
+                    material = kMaterialBet;
+                    clear_run = 0;
+                } else if (material) {
+                    clear_run++;
+                    if (clear_run >= kClearRun) {
+                        material = false;
+                        in_air = false;
+                    }
                 }
             }
-            t -= 1;
+            t -= taps;
         }
+        // 3. early termination, tested every few rounds for all lanes at once: the test costs about as
+        //    much as half a tap and the whole wave pays for it whenever a single lane runs it
+        if ((round & (kDecideEvery - 1)) == kDecideEvery - 1 && fast_ok && marching && Tr < 0.03125) {
+            if (try_decide(t + 1)) {     // taps t .. 0 are still to come
+                decided = true;
+                marching = false;
+            }
+        }
+#ifdef VR_DIAG
+        diag_sample += clock64() - diag_r1;
+#endif
     }
 
     if (marching) {
-        // out of budget with taps left: a wave continues this ray (k_march_long)
+        // out of budget with taps left: the next pass continues this ray
         LongRay e;
         e.pixel_id = pixel_id; e.t = t; e.S = S; e.pad_ = 0.0f;
         e.F0 = F0; e.F1 = F1; e.F2 = F2; e.Tr = Tr;
-        long_queue[atomicAdd(&ctr->long_count, 1u)] = e;
+        next_queue[atomicAdd(next_count, 1u)] = e;
     } else if (in_rect) {
         if (r.hit && !decided) {
             // back-most tap: its colour enters unweighted by its alpha (VolumeRendering.comp:189-191)
@@ -766,7 +867,7 @@ __global__ __launch_bounds__(256, VR_FAST_MIN_WAVES) void k_march_fast(VolumeVie
         if (!r.hit || decided) out[pixel_id] = rgba;
     }
     if (STATS && in_rect) {
-        atomicAdd(&ctr->rays_hit, r.hit ? 1ull : 0ull);
+        if (!RESUME) atomicAdd(&ctr->rays_hit, r.hit ? 1ull : 0ull);
         atomicAdd(&ctr->samples_evaluated, evaluated);
         atomicAdd(&ctr->cells_read, lookups);
     }
@@ -779,26 +880,174 @@ __global__ __launch_bounds__(256, VR_FAST_MIN_WAVES) void k_march_fast(VolumeVie
         diag_both = max(diag_both, (unsigned int)__shfl_xor((int)diag_both, o));
         diag_sum += (unsigned int)__shfl_xor((int)diag_sum, o);
     }
-    if (g_vr_timeline && (threadIdx.x & 63) == 0) {
+    if (g_vr_timeline && !RESUME && (threadIdx.x & 63) == 0) {
         const unsigned long long wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
         unsigned int hw;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         unsigned int xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        g_vr_timeline[wave_id * 4 + 0] = diag_t0;
-        g_vr_timeline[wave_id * 4 + 1] = wall_clock64();
-        g_vr_timeline[wave_id * 4 + 2] = ((unsigned long long)xcc << 32) | hw;
-        g_vr_timeline[wave_id * 4 + 3] = (unsigned long long)diag_rounds | ((unsigned long long)diag_model << 12) |
+        g_vr_timeline[wave_id * 8 + 4] = (unsigned long long)diag_setup;
+        g_vr_timeline[wave_id * 8 + 5] = (unsigned long long)diag_skip;
+        g_vr_timeline[wave_id * 8 + 6] = (unsigned long long)diag_sample;
+        g_vr_timeline[wave_id * 8 + 7] = (unsigned long long)(clock64() - diag_c0);
+        g_vr_timeline[wave_id * 8 + 0] = diag_t0;
+        g_vr_timeline[wave_id * 8 + 1] = wall_clock64();
+        g_vr_timeline[wave_id * 8 + 2] = ((unsigned long long)xcc << 32) | hw;
+        g_vr_timeline[wave_id * 8 + 3] = (unsigned long long)diag_rounds | ((unsigned long long)diag_model << 12) |
                                          ((unsigned long long)diag_exact << 24) | ((unsigned long long)diag_both << 36) |
                                          ((unsigned long long)diag_sum << 48);
     }
 #endif
 }
 
-// Continuation of the rays k_march_fast ran out of budget on, one wave per ray.  The 64 lanes
-// fetch 64 consecutive taps at once (or the whole wave steps over an empty cube), then the taps
-// with a non-zero alpha are folded front to back in tap order, exactly the accumulation
-// k_march_fast does one tap at a time; the decision test runs once per 64 taps.
+template <typename T, bool STATS>
+__global__ __launch_bounds__(256, VR_FAST_MIN_WAVES) void k_march_fast(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
+                                                   float4 border, const LutInfo *__restrict__ info,
+                                                   uint32_t *__restrict__ out, Counters *ctr, uint32_t *touched,
+                                                   uint32_t *__restrict__ queue, LongRay *__restrict__ long_queue, int budget)
+{
+    __shared__ float4 s_lut[kLutLds];
+    stage_lut(s_lut, lut, border);
+    const Decider dec(info);
+    int px, py;
+    uint32_t pixel_id;
+    const bool in_rect = lane_pixel(fp, px, py, pixel_id);
+    march_lanes<T, STATS, false>(vol, fp, s_lut, dec, out, ctr, touched, queue, long_queue, &ctr->long_count, budget, in_rect, px,
+                                 py, pixel_id, LongRay{});
+}
+
+// What a run of consecutive taps does to the light behind it, taken front to back from full
+// transmittance: colour sum f, transmittance tr, and s = sum of the transmittance in front of each of
+// its taps with a != 0 (the weight of their rounding errors).  Runs concatenate associatively.
+struct Blend {
+    double f0, f1, f2, tr;
+    float s;
+};
+__device__ __forceinline__ Blend blend_of_tap(bool on, const float4 &tf)
+{
+    const double a = on ? (double)tf.w : 0.0;
+    return Blend{a * (double)tf.x, a * (double)tf.y, a * (double)tf.z, 1.0 - a, on ? 1.0f : 0.0f};
+}
+__device__ __forceinline__ void blend_under(Blend &front, const Blend &back)
+{
+    front.f0 = __builtin_fma(front.tr, back.f0, front.f0);
+    front.f1 = __builtin_fma(front.tr, back.f1, front.f1);
+    front.f2 = __builtin_fma(front.tr, back.f2, front.f2);
+    front.s = front.s + (float)front.tr * back.s;
+    front.tr = front.tr * back.tr;
+}
+constexpr int kSerialFoldMax = 10;   // up to this many taps of a 64-tap chunk are blended one by one
+
+// Continuation of a ray k_march_fast ran out of budget on, by a whole wave.  The 64 lanes fetch 64
+// consecutive taps at once (or the whole wave steps over an empty cube), then the taps with a
+// non-zero alpha are blended front to back in tap order, the accumulation k_march_fast does one tap
+// at a time; the decision test runs once per 64 taps.  Returns whether the bytes are decided.
+template <typename T, bool STATS>
+__device__ __forceinline__ bool continue_ray(const VolumeView &vol, const FrameParams &fp, const float4 *s_lut,
+                                             const Decider &dec, Counters *ctr, uint32_t *touched, const LongRay &e,
+                                             uint32_t &rgba)
+{
+    const int lane = threadIdx.x & 63;
+    int px, py;
+    pixel_of_index(fp, e.pixel_id, px, py);
+    const Ray r = make_ray(fp, px, py);          // identical in every lane
+    const int last = fp.samples + 1;
+    const float step = (r.tmax - r.tmin) / (float)(uint32_t)last;
+    const RayModel rm = ray_model(r, vol, step, -1.0f);
+    double F0 = e.F0, F1 = e.F1, F2 = e.F2, Tr = e.Tr;
+    float S = e.S;
+    int t = e.t;
+    bool decided = false;
+    rgba = 0xff000000u;
+    unsigned long long evaluated = 0;
+    if (t > rm.t_first) t = rm.t_first;
+    while (t >= rm.t_stop && !decided) {
+        const int n = empty_span(vol, rm, t);   // wave-uniform
+        if (n > 0) {
+            t -= n;
+            continue;
+        }
+        const int tt = t - lane;
+        bool fetch = tt >= rm.t_stop;
+        Cell c;
+        uint32_t brick = 0;
+        if (fetch) {
+            const Tap p = tap_position(r, vol, step, tt);
+            c = tap_cell(p, vol);
+            brick = brick_of(c, vol);
+            if (brick_empty(brick, vol) || micro_empty(vol.micro[brick], c)) fetch = false;
+        }
+        float4 tf = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (fetch) {
+            tf = sample_tf(s_lut, sample_volume<T>(c, brick, vol));
+            if (STATS) {
+                evaluated++;
+                atomicOr(&touched[brick >> 5], 1u << (brick & 31));
+            }
+        }
+        const bool on = fetch && tf.w != 0.0f;
+        unsigned long long todo = __ballot(on);
+        if (__popcll(todo) > kSerialFoldMax) {
+            // many taps to blend: "front over back" is associative, so the 64 lanes reduce in six
+            // shuffle steps instead of one tap at a time (lane 0 holds the front-most tap)
+            Blend v = blend_of_tap(on, tf);
+            for (int o = 1; o < 64; o <<= 1) {
+                Blend back;
+                back.f0 = __shfl_down(v.f0, o);
+                back.f1 = __shfl_down(v.f1, o);
+                back.f2 = __shfl_down(v.f2, o);
+                back.tr = __shfl_down(v.tr, o);
+                back.s = __shfl_down(v.s, o);
+                blend_under(v, back);   // lanes whose partner lies beyond the wave never feed lane 0
+            }
+            Blend all;
+            all.f0 = __shfl(v.f0, 0);
+            all.f1 = __shfl(v.f1, 0);
+            all.f2 = __shfl(v.f2, 0);
+            all.tr = __shfl(v.tr, 0);
+            all.s = __shfl(v.s, 0);
+            F0 = __builtin_fma(Tr, all.f0, F0);
+            F1 = __builtin_fma(Tr, all.f1, F1);
+            F2 = __builtin_fma(Tr, all.f2, F2);
+            S += (float)Tr * all.s * 1.000001f;
+            Tr = Tr * all.tr;
+        } else {
+            while (todo) {
+                const int src = __builtin_ctzll(todo);   // lowest lane = front-most tap of the chunk
+                todo &= todo - 1;
+                const double a = (double)__shfl(tf.w, src);
+                const double w = Tr * a;
+                F0 = __builtin_fma(w, (double)__shfl(tf.x, src), F0);
+                F1 = __builtin_fma(w, (double)__shfl(tf.y, src), F1);
+                F2 = __builtin_fma(w, (double)__shfl(tf.z, src), F2);
+                S += (float)Tr;
+                Tr = Tr * (1.0 - a);
+            }
+        }
+        t -= 64;
+        if (dec.ok && Tr < 0.03125) decided = dec.decide(F0, F1, F2, Tr, S, (t > 0 ? t : 0) + 1, rgba);
+    }
+    if (!decided) {
+        // back-most tap: its colour enters unweighted by its alpha (VolumeRendering.comp:189-191)
+        const Tap p = tap_position(r, vol, step, 0);
+        const Cell c = tap_cell(p, vol);
+        const uint32_t brick = brick_of(c, vol);
+        const float4 tf = sample_tf(s_lut, sample_volume<T>(c, brick, vol));
+        if (STATS && lane == 0) {
+            evaluated++;
+            atomicOr(&touched[brick >> 5], 1u << (brick & 31));
+        }
+        F0 = __builtin_fma(Tr, (double)tf.x, F0);
+        F1 = __builtin_fma(Tr, (double)tf.y, F1);
+        F2 = __builtin_fma(Tr, (double)tf.z, F2);
+        decided = dec.ok && dec.decide(F0, F1, F2, 0.0, S, 0, rgba);
+    }
+    if (STATS) atomicAdd(&ctr->samples_evaluated, evaluated);
+    return decided;
+}
+
+// The rays k_march_fast ran out of lane budget on, one wave per ray; rays still undecided at the back
+// join the replay queue.
 template <typename T, bool STATS>
 __global__ __launch_bounds__(256) void k_march_long(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
                                                    float4 border, const LutInfo *__restrict__ info,
@@ -813,79 +1062,27 @@ __global__ __launch_bounds__(256) void k_march_long(VolumeView vol, FrameParams 
     const uint32_t entries = ctr->long_count;
     for (uint32_t entry = blockIdx.x * 4u + (threadIdx.x >> 6); entry < entries; entry += waves) {
         const LongRay e = long_queue[entry];
-        int px, py;
-        pixel_of_index(fp, e.pixel_id, px, py);
-        const Ray r = make_ray(fp, px, py);          // identical in every lane
-        const int last = fp.samples + 1;
-        const float step = (r.tmax - r.tmin) / (float)(uint32_t)last;
-        const RayModel rm = ray_model(r, vol, step, -1.0f);
-        double F0 = e.F0, F1 = e.F1, F2 = e.F2, Tr = e.Tr;
-        float S = e.S;
-        int t = e.t;
-        bool decided = false;
-        uint32_t rgba = 0xff000000u;
-        unsigned long long evaluated = 0;
-        if (t > rm.t_first) t = rm.t_first;
-        while (t >= rm.t_stop && !decided) {
-            const int n = empty_span(vol, rm, t);   // wave-uniform
-            if (n > 0) {
-                t -= n;
-                continue;
-            }
-            const int tt = t - lane;
-            bool fetch = tt >= rm.t_stop;
-            Cell c;
-            uint32_t brick = 0;
-            if (fetch) {
-                const Tap p = tap_position(r, vol, step, tt);
-                c = tap_cell(p, vol);
-                brick = brick_of(c, vol);
-                if (brick_empty(brick, vol) || micro_empty(vol.micro[brick], c)) fetch = false;
-            }
-            float4 tf = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (fetch) {
-                tf = sample_tf(s_lut, sample_volume<T>(c, brick, vol));
-                if (STATS) {
-                    evaluated++;
-                    atomicOr(&touched[brick >> 5], 1u << (brick & 31));
-                }
-            }
-            unsigned long long todo = __ballot(fetch && tf.w != 0.0f);
-            while (todo) {
-                const int src = __builtin_ctzll(todo);   // lowest lane = front-most tap of the chunk
-                todo &= todo - 1;
-                const double a = (double)__shfl(tf.w, src);
-                const double w = Tr * a;
-                F0 = __builtin_fma(w, (double)__shfl(tf.x, src), F0);
-                F1 = __builtin_fma(w, (double)__shfl(tf.y, src), F1);
-                F2 = __builtin_fma(w, (double)__shfl(tf.z, src), F2);
-                S += (float)Tr;
-                Tr = Tr * (1.0 - a);
-            }
-            t -= 64;
-            if (dec.ok && Tr < 0.03125) decided = dec.decide(F0, F1, F2, Tr, S, (t > 0 ? t : 0) + 1, rgba);
-        }
-        if (!decided) {
-            // back-most tap: its colour enters unweighted by its alpha (VolumeRendering.comp:189-191)
-            const Tap p = tap_position(r, vol, step, 0);
-            const Cell c = tap_cell(p, vol);
-            const uint32_t brick = brick_of(c, vol);
-            const float4 tf = sample_tf(s_lut, sample_volume<T>(c, brick, vol));
-            if (STATS && lane == 0) {
-                evaluated++;
-                atomicOr(&touched[brick >> 5], 1u << (brick & 31));
-            }
-            F0 = __builtin_fma(Tr, (double)tf.x, F0);
-            F1 = __builtin_fma(Tr, (double)tf.y, F1);
-            F2 = __builtin_fma(Tr, (double)tf.z, F2);
-            decided = dec.ok && dec.decide(F0, F1, F2, 0.0, S, 0, rgba);
-        }
+        uint32_t rgba;
+        const bool decided = continue_ray<T, STATS>(vol, fp, s_lut, dec, ctr, touched, e, rgba);
         if (lane == 0) {
             if (decided) out[e.pixel_id] = rgba;
             else queue[atomicAdd(&ctr->replay_count, 1u)] = e.pixel_id;
         }
-        if (STATS) atomicAdd(&ctr->samples_evaluated, evaluated);
     }
+}
+
+// The rays neither march could decide, re-marched in reference order, one wave per ray.
+template <typename T, bool STATS>
+__global__ __launch_bounds__(256) void k_replay_exact(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
+                                                     float4 border, uint32_t *__restrict__ out, Counters *ctr,
+                                                     uint32_t *touched, const uint32_t *__restrict__ queue)
+{
+    __shared__ float4 s_lut[kLutLds];
+    stage_lut(s_lut, lut, border);
+    const uint32_t waves = gridDim.x * 4u;
+    const uint32_t entries = ctr->replay_count;
+    for (uint32_t entry = blockIdx.x * 4u + (threadIdx.x >> 6); entry < entries; entry += waves)
+        replay_ray<T, STATS>(vol, fp, s_lut, out, ctr, touched, queue[entry]);
 }
 
 // Rays of the rectangle that hit the box (the reference marches samples + 2 taps on each).
