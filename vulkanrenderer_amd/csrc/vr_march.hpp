@@ -468,78 +468,6 @@ __global__ __launch_bounds__(256) void k_march_exact(VolumeView vol, FrameParams
     }
 }
 
-// Reference-order march of one ray by a whole wave: the fast march hands over the few rays whose
-// bytes it could not decide, far too few to fill the chip with one lane each.  The 64 lanes fetch 64
-// consecutive taps at once; the blend itself is inherently serial, so the lanes' (alpha, colour) are
-// then folded in tap order with the shader's expression.  Taps with alpha exactly 0 and a finite
-// colour are identities and are left out of the fold; the back-most tap assigns.
-template <typename T, bool STATS>
-__device__ __forceinline__ void replay_ray(const VolumeView &vol, const FrameParams &fp, const float4 *s_lut,
-                                           uint32_t *__restrict__ out, Counters *ctr, uint32_t *touched, uint32_t out_index)
-{
-    const int lane = threadIdx.x & 63;
-    int px, py;
-    pixel_of_index(fp, out_index, px, py);
-    const Ray r = make_ray(fp, px, py);          // identical in every lane
-    const int last = fp.samples + 1;
-    const float step = (r.tmax - r.tmin) / (float)(uint32_t)last;
-    const RayModel rm = ray_model(r, vol, step, 1.0f);
-    float cr = 0.0f, cg = 0.0f, cb = 0.0f;
-    unsigned long long evaluated = 0;
-    int base = 0;
-    while (base <= last) {
-        if (base > 0) {
-            if (base < rm.t_stop) base = rm.t_stop;    // nothing occupied before or beyond these taps
-            if (base > rm.t_first || base > last) break;
-            const int n = empty_span(vol, rm, base);   // wave-uniform: whole runs of empty taps
-            if (n > 0) {
-                base += n;
-                continue;
-            }
-        }
-        const int t = base + lane;
-        bool fetch = t <= last;
-        Cell c;
-        uint32_t brick = 0;
-        if (fetch) {
-            const Tap p = tap_position(r, vol, step, t);
-            c = tap_cell(p, vol);
-            brick = brick_of(c, vol);
-            if (t > 0 && (brick_empty(brick, vol) || micro_empty(vol.micro[brick], c))) fetch = false;
-        }
-        float4 tf = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (fetch) {
-            tf = sample_tf(s_lut, sample_volume<T>(c, brick, vol));
-            if (STATS) {
-                evaluated++;
-                atomicOr(&touched[brick >> 5], 1u << (brick & 31));
-            }
-        }
-        const bool identity = tf.w == 0.0f && isfinite(tf.x) && isfinite(tf.y) && isfinite(tf.z);
-        unsigned long long todo = __ballot(fetch && (t == 0 || !identity));
-        while (todo) {
-            const int src = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            const float a = __shfl(tf.w, src), x = __shfl(tf.x, src), y = __shfl(tf.y, src), z = __shfl(tf.z, src);
-            if (base + src == 0) {
-                cr = x; cg = y; cb = z;
-            } else {
-                const float ia = 1.0f - a;
-                cr = a * x + ia * cr;
-                cg = a * y + ia * cg;
-                cb = a * z + ia * cb;
-            }
-        }
-        base += 64;
-    }
-    if (!r.hit) { cr = cg = cb = 0.0f; }
-    if (lane == 0) out[out_index] = pack_rgba8(cr, cg, cb);
-    if (STATS) {
-        if (lane == 0) atomicAdd(&ctr->replay_rays, 1ull);
-        atomicAdd(&ctr->samples_evaluated, evaluated);
-    }
-}
-
 // ---- deciding a pixel before the ray is finished -------------------------------------------------
 // See k_march_fast for the argument.  decide() returns true and the final bytes when, for all
 // three channels, both ends of the interval that must contain the shader's float result convert to
@@ -577,6 +505,146 @@ struct Decider {
         return same;
     }
 };
+
+// Reference-order march of one ray by a whole wave: the fast march hands over the few rays whose
+// bytes it could not decide, far too few to fill the chip with one lane each.  The 64 lanes fetch 64
+// consecutive taps at once; the blend itself is inherently serial, so the lanes' (alpha, colour) are
+// then folded in tap order with the shader's expression.  Taps with alpha exactly 0 and a finite
+// colour are identities and are left out of the fold; the back-most tap assigns.
+//
+// The fold need not start at the back.  One blend step C' = fl(fl(a c) + fl(fl(1 - a) C)) is, for
+// 0 <= a <= 1, a non-decreasing function of C in float arithmetic (every rounding is monotone), so two
+// folds started at tap m from a lower and an upper bound of the colour behind it enclose the shader's
+// colour after every tap.  The two differ by the start width times the transmittance of the taps
+// folded, so behind enough material they arrive at the front as the same float: then that float is the
+// shader's result, whatever lies behind m.  A first pass from the eye finds the tap where the
+// transmittance drops below 2^-40; if the two folds from there do not meet, the ray is folded from
+// the back after all.  Needs alphas in [0,1] and finite colours (Decider::ok).
+constexpr double kReplayDark = 0x1p-40;
+
+template <typename T, bool STATS>
+__device__ __forceinline__ void replay_ray(const VolumeView &vol, const FrameParams &fp, const float4 *s_lut,
+                                           const Decider &dec, uint32_t *__restrict__ out, Counters *ctr,
+                                           uint32_t *touched, uint32_t out_index)
+{
+    const int lane = threadIdx.x & 63;
+    int px, py;
+    pixel_of_index(fp, out_index, px, py);
+    const Ray r = make_ray(fp, px, py);          // identical in every lane
+    const int last = fp.samples + 1;
+    const float step = (r.tmax - r.tmin) / (float)(uint32_t)last;
+    unsigned long long evaluated = 0;
+
+    // from the eye: where does the ray go dark?
+    int start = 0;
+    if (dec.ok && r.hit) {
+        const RayModel fm = ray_model(r, vol, step, -1.0f);
+        double tr = 1.0;
+        int t = last < fm.t_first ? last : fm.t_first;
+        while (t >= fm.t_stop && !(tr < kReplayDark)) {
+            const int n = empty_span(vol, fm, t);   // wave-uniform
+            if (n > 0) {
+                t -= n;
+                continue;
+            }
+            const int tt = t - lane;
+            double keep = 1.0;
+            if (tt >= fm.t_stop) {
+                const Cell c = tap_cell(tap_position(r, vol, step, tt), vol);
+                const uint32_t brick = brick_of(c, vol);
+                if (!(brick_empty(brick, vol) || micro_empty(vol.micro[brick], c))) {
+                    keep = 1.0 - (double)sample_tf(s_lut, sample_volume<T>(c, brick, vol)).w;
+                    if (STATS) {
+                        evaluated++;
+                        atomicOr(&touched[brick >> 5], 1u << (brick & 31));
+                    }
+                }
+            }
+            for (int o = 32; o > 0; o >>= 1) keep *= __shfl_xor(keep, o);
+            tr *= keep;
+            t -= 64;
+        }
+        if (tr < kReplayDark) start = t + 1 > 1 ? t + 1 : 1;   // every tap in front of t + 1 was part of the product
+    }
+
+    const RayModel rm = ray_model(r, vol, step, 1.0f);
+    float lo[3] = {0.0f, 0.0f, 0.0f}, hi[3] = {0.0f, 0.0f, 0.0f};
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if (start > 0) {
+            // bounds of the colour behind tap `start`: colours stay inside the table's range up to the
+            // rounding of the steps taken, at most 3 ulp of the largest colour each
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float mag = fmaxf(fabsf(dec.cmin[c]), fabsf(dec.cmax[c]));
+                const float slack = mag * (2e-3f + 4.0f * kUlpHalf * (float)(last + 1)) + 1e-30f;
+                lo[c] = dec.cmin[c] - slack;
+                hi[c] = dec.cmax[c] + slack;
+            }
+        } else {
+            lo[0] = lo[1] = lo[2] = hi[0] = hi[1] = hi[2] = 0.0f;
+        }
+        int base = start;
+        while (base <= last) {
+            if (base > 0) {
+                if (base < rm.t_stop) base = rm.t_stop;    // nothing occupied before or beyond these taps
+                if (base > rm.t_first || base > last) break;
+                const int n = empty_span(vol, rm, base);   // wave-uniform: whole runs of empty taps
+                if (n > 0) {
+                    base += n;
+                    continue;
+                }
+            }
+            const int t = base + lane;
+            bool fetch = t <= last;
+            Cell c;
+            uint32_t brick = 0;
+            if (fetch) {
+                const Tap p = tap_position(r, vol, step, t);
+                c = tap_cell(p, vol);
+                brick = brick_of(c, vol);
+                if (t > 0 && (brick_empty(brick, vol) || micro_empty(vol.micro[brick], c))) fetch = false;
+            }
+            float4 tf = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (fetch) {
+                tf = sample_tf(s_lut, sample_volume<T>(c, brick, vol));
+                if (STATS) {
+                    evaluated++;
+                    atomicOr(&touched[brick >> 5], 1u << (brick & 31));
+                }
+            }
+            const bool identity = tf.w == 0.0f && isfinite(tf.x) && isfinite(tf.y) && isfinite(tf.z);
+            unsigned long long todo = __ballot(fetch && (t == 0 || !identity));
+            while (todo) {
+                const int src = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const float a = __shfl(tf.w, src), x = __shfl(tf.x, src), y = __shfl(tf.y, src), z = __shfl(tf.z, src);
+                if (base + src == 0) {
+                    lo[0] = hi[0] = x; lo[1] = hi[1] = y; lo[2] = hi[2] = z;
+                } else {
+                    const float ia = 1.0f - a;
+                    const float ax = a * x, ay = a * y, az = a * z;
+                    lo[0] = ax + ia * lo[0];
+                    lo[1] = ay + ia * lo[1];
+                    lo[2] = az + ia * lo[2];
+                    hi[0] = ax + ia * hi[0];
+                    hi[1] = ay + ia * hi[1];
+                    hi[2] = az + ia * hi[2];
+                }
+            }
+            base += 64;
+        }
+        const bool met = __float_as_uint(lo[0]) == __float_as_uint(hi[0]) && __float_as_uint(lo[1]) == __float_as_uint(hi[1]) &&
+                         __float_as_uint(lo[2]) == __float_as_uint(hi[2]);
+        if (start == 0 || met) break;
+        start = 0;   // the two folds did not meet: fold the whole ray
+    }
+    if (!r.hit) { lo[0] = lo[1] = lo[2] = 0.0f; }
+    if (lane == 0) out[out_index] = pack_rgba8(lo[0], lo[1], lo[2]);
+    if (STATS) {
+        if (lane == 0) atomicAdd(&ctr->replay_rays, 1ull);
+        atomicAdd(&ctr->samples_evaluated, evaluated);
+    }
+}
 
 // A ray the lane-per-ray march hands over to a whole wave: where it stands and what it has
 // accumulated (k_march_fast -> k_march_long).
@@ -1074,15 +1142,17 @@ __global__ __launch_bounds__(256) void k_march_long(VolumeView vol, FrameParams 
 // The rays neither march could decide, re-marched in reference order, one wave per ray.
 template <typename T, bool STATS>
 __global__ __launch_bounds__(256) void k_replay_exact(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
-                                                     float4 border, uint32_t *__restrict__ out, Counters *ctr,
-                                                     uint32_t *touched, const uint32_t *__restrict__ queue)
+                                                     float4 border, const LutInfo *__restrict__ info,
+                                                     uint32_t *__restrict__ out, Counters *ctr, uint32_t *touched,
+                                                     const uint32_t *__restrict__ queue)
 {
     __shared__ float4 s_lut[kLutLds];
     stage_lut(s_lut, lut, border);
+    const Decider dec(info);
     const uint32_t waves = gridDim.x * 4u;
     const uint32_t entries = ctr->replay_count;
     for (uint32_t entry = blockIdx.x * 4u + (threadIdx.x >> 6); entry < entries; entry += waves)
-        replay_ray<T, STATS>(vol, fp, s_lut, out, ctr, touched, queue[entry]);
+        replay_ray<T, STATS>(vol, fp, s_lut, dec, out, ctr, touched, queue[entry]);
 }
 
 // Rays of the rectangle that hit the box (the reference marches samples + 2 taps on each).
