@@ -1004,7 +1004,11 @@ __device__ __forceinline__ void blend_under(Blend &front, const Blend &back)
     front.s = front.s + (float)front.tr * back.s;
     front.tr = front.tr * back.tr;
 }
-constexpr int kSerialFoldMax = 10;   // up to this many taps of a 64-tap chunk are blended one by one
+constexpr int kSerialFoldMax = 8;    // up to this many lanes' taps of a chunk are blended one lane after the other
+#ifndef VR_LONG_TAPS
+#define VR_LONG_TAPS 2
+#endif
+constexpr int kLongTaps = VR_LONG_TAPS;   // consecutive taps per lane and round in the wave-per-ray march
 
 // Continuation of a ray k_march_fast ran out of budget on, by a whole wave.  The 64 lanes fetch 64
 // consecutive taps at once (or the whole wave steps over an empty cube), then the taps with a
@@ -1035,30 +1039,39 @@ __device__ __forceinline__ bool continue_ray(const VolumeView &vol, const FrameP
             t -= n;
             continue;
         }
-        const int tt = t - lane;
-        bool fetch = tt >= rm.t_stop;
-        Cell c;
-        uint32_t brick = 0;
-        if (fetch) {
-            const Tap p = tap_position(r, vol, step, tt);
-            c = tap_cell(p, vol);
-            brick = brick_of(c, vol);
-            if (brick_empty(brick, vol) || micro_empty(vol.micro[brick], c)) fetch = false;
+        // lane l takes the kLongTaps consecutive taps t - l * kLongTaps - k; their loads are in flight together
+        Cell cs[kLongTaps];
+        uint32_t bricks[kLongTaps];
+        bool fetch[kLongTaps];
+#pragma unroll
+        for (int k = 0; k < kLongTaps; k++) {
+            const int tt = t - (lane * kLongTaps + k);
+            fetch[k] = tt >= rm.t_stop;
+            cs[k] = tap_cell(tap_position(r, vol, step, fetch[k] ? tt : rm.t_stop), vol);
+            bricks[k] = brick_of(cs[k], vol);
         }
-        float4 tf = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (fetch) {
-            tf = sample_tf(s_lut, sample_volume<T>(c, brick, vol));
+#pragma unroll
+        for (int k = 0; k < kLongTaps; k++)
+            if (fetch[k] && (brick_empty(bricks[k], vol) || micro_empty(vol.micro[bricks[k]], cs[k]))) fetch[k] = false;
+        TapWords raw[kLongTaps];
+#pragma unroll
+        for (int k = 0; k < kLongTaps; k++)
+            if (fetch[k]) raw[k] = fetch_volume<T>(cs[k], bricks[k], vol);
+        Blend v{0.0, 0.0, 0.0, 1.0, 0.0f};
+#pragma unroll
+        for (int k = 0; k < kLongTaps; k++) {
+            if (!fetch[k]) continue;
+            const float4 tf = sample_tf(s_lut, filter_volume<T>(raw[k], cs[k], vol));
             if (STATS) {
                 evaluated++;
-                atomicOr(&touched[brick >> 5], 1u << (brick & 31));
+                atomicOr(&touched[bricks[k] >> 5], 1u << (bricks[k] & 31));
             }
+            if (tf.w != 0.0f) blend_under(v, blend_of_tap(true, tf));
         }
-        const bool on = fetch && tf.w != 0.0f;
-        unsigned long long todo = __ballot(on);
+        unsigned long long todo = __ballot(v.s != 0.0f);
         if (__popcll(todo) > kSerialFoldMax) {
             // many taps to blend: "front over back" is associative, so the 64 lanes reduce in six
-            // shuffle steps instead of one tap at a time (lane 0 holds the front-most tap)
-            Blend v = blend_of_tap(on, tf);
+            // shuffle steps instead of one lane at a time (lane 0 holds the front-most taps)
             for (int o = 1; o < 64; o <<= 1) {
                 Blend back;
                 back.f0 = __shfl_down(v.f0, o);
@@ -1068,31 +1081,24 @@ __device__ __forceinline__ bool continue_ray(const VolumeView &vol, const FrameP
                 back.s = __shfl_down(v.s, o);
                 blend_under(v, back);   // lanes whose partner lies beyond the wave never feed lane 0
             }
-            Blend all;
-            all.f0 = __shfl(v.f0, 0);
-            all.f1 = __shfl(v.f1, 0);
-            all.f2 = __shfl(v.f2, 0);
-            all.tr = __shfl(v.tr, 0);
-            all.s = __shfl(v.s, 0);
-            F0 = __builtin_fma(Tr, all.f0, F0);
-            F1 = __builtin_fma(Tr, all.f1, F1);
-            F2 = __builtin_fma(Tr, all.f2, F2);
-            S += (float)Tr * all.s * 1.000001f;
-            Tr = Tr * all.tr;
-        } else {
-            while (todo) {
-                const int src = __builtin_ctzll(todo);   // lowest lane = front-most tap of the chunk
-                todo &= todo - 1;
-                const double a = (double)__shfl(tf.w, src);
-                const double w = Tr * a;
-                F0 = __builtin_fma(w, (double)__shfl(tf.x, src), F0);
-                F1 = __builtin_fma(w, (double)__shfl(tf.y, src), F1);
-                F2 = __builtin_fma(w, (double)__shfl(tf.z, src), F2);
-                S += (float)Tr;
-                Tr = Tr * (1.0 - a);
-            }
+            todo = 1ull;
         }
-        t -= 64;
+        while (todo) {
+            const int src = __builtin_ctzll(todo);   // lowest lane = front-most taps of the chunk
+            todo &= todo - 1;
+            Blend part;
+            part.f0 = __shfl(v.f0, src);
+            part.f1 = __shfl(v.f1, src);
+            part.f2 = __shfl(v.f2, src);
+            part.tr = __shfl(v.tr, src);
+            part.s = __shfl(v.s, src);
+            F0 = __builtin_fma(Tr, part.f0, F0);
+            F1 = __builtin_fma(Tr, part.f1, F1);
+            F2 = __builtin_fma(Tr, part.f2, F2);
+            S += (float)Tr * part.s * 1.000001f;
+            Tr = Tr * part.tr;
+        }
+        t -= 64 * kLongTaps;
         if (dec.ok && Tr < 0.03125) decided = dec.decide(F0, F1, F2, Tr, S, (t > 0 ? t : 0) + 1, rgba);
     }
     if (!decided) {
