@@ -39,6 +39,12 @@ struct vr_ctx {
     unsigned long long *micro = nullptr;  // per brick: bits of its 2^3-cell blocks
     int *occ = nullptr;                   // bounding box of the occupied bricks (6 ints)
     uint32_t *skip = nullptr;             // per brick: 2-bit code of the coarsest empty cube around it
+    uint32_t *occ_list = nullptr;         // indices of the occupied bricks, for the per-tile depth ranges
+    uint32_t *d_occ_count = nullptr;
+    uint32_t occ_count = 0;
+    uint2 *tiles = nullptr;               // per 32x32 pixel tile: depth range of the occupied bricks (fast mode)
+    size_t tiles_cap = 0;
+    bool tile_clip = true;
     bool occupancy_dirty = true;
     int dtype = 0, nx = 0, ny = 0, nz = 0, nbx = 0, nby = 0, nbz = 0;
     // sort-last: the bricks held are the box [brick_lo, brick_lo + (nbx, nby, nbz)) of the volume's grid
@@ -112,8 +118,11 @@ void release_volume(vr_ctx *ctx)
     }
     if (ctx->micro) (void)hipFree(ctx->micro);
     if (ctx->skip) (void)hipFree(ctx->skip);
+    if (ctx->occ_list) (void)hipFree(ctx->occ_list);
     ctx->micro = nullptr;
     ctx->skip = nullptr;
+    ctx->occ_list = nullptr;
+    ctx->occ_count = 0;
     ctx->bricks = nullptr;
     ctx->cells = nullptr;
     ctx->touched = nullptr;
@@ -237,6 +246,7 @@ int ingest_device(vr_ctx *ctx, T *d_raw, int nx, int ny, int nz, float max_value
     }
     VR_HIP(ctx, hipMalloc(&ctx->micro, ctx->brick_count * sizeof(unsigned long long)));
     VR_HIP(ctx, hipMalloc(&ctx->skip, ((ctx->brick_count + 15) / 16) * sizeof(uint32_t)));
+    VR_HIP(ctx, hipMalloc(&ctx->occ_list, ctx->brick_count * sizeof(uint32_t)));
     ctx->occupancy_dirty = true;
     const unsigned brick_blocks = (unsigned)std::min<size_t>(ctx->brick_count, 1u << 20);
     hipLaunchKernelGGL((vr::k_build_bricks<T>), dim3(brick_blocks), dim3(256), 0, ctx->stream, (const T *)d_raw,
@@ -283,7 +293,12 @@ int refresh_occupancy(vr_ctx *ctx)
     else
         hipLaunchKernelGGL((vr::k_classify_micro<uint16_t>), dim3(micro_blocks), dim3(256), 0, ctx->stream, (const uint16_t *)ctx->bricks,
                            ctx->empty[0], bricks, ctx->inv_hi, ctx->inv_lo, ctx->lut_info, ctx->micro);
+    VR_HIP(ctx, hipMemsetAsync(ctx->d_occ_count, 0, sizeof(uint32_t), ctx->stream));
+    hipLaunchKernelGGL(vr::k_list_occupied, dim3((bricks + 255) / 256), dim3(256), 0, ctx->stream, ctx->empty[0], bricks, ctx->occ_list,
+                       ctx->d_occ_count);
     VR_HIP(ctx, hipGetLastError());
+    VR_HIP(ctx, hipMemcpyAsync(&ctx->occ_count, ctx->d_occ_count, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    VR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->occupancy_dirty = false;
     return VR_OK;
 }
@@ -331,15 +346,26 @@ void launch_frame(vr_ctx *ctx, const vr::FrameParams &fp, uint32_t *d_out, bool 
             hipLaunchKernelGGL((vr::k_march_exact<T, true, false>), grid, block, 0, s, vol, fp, lut, border, d_out, ctx->counters, ctx->touched);
         (void)hipEventRecord(ctx->ring_b[slot], s);
     } else {
-        // front-to-back march, then the rays it could not finish or decide, one wave per ray
+        // depth range of the occupied bricks per tile of the frame, then the front-to-back march, then the
+        // rays it could not finish or decide, one wave per ray
+        const int tile_px = 1 << vr::kRangeShift;
+        const int tiles_x = (fp.width + tile_px - 1) / tile_px, tiles_y = (fp.height + tile_px - 1) / tile_px;
+        const uint2 *tiles = nullptr;
+        if (ctx->tile_clip && ctx->tiles && ctx->occ_count > 0) {
+            (void)hipMemsetAsync(ctx->tiles, 0, (size_t)tiles_x * tiles_y * sizeof(uint2), s);
+            hipLaunchKernelGGL(vr::k_splat_bricks, dim3((ctx->occ_count + 255) / 256), dim3(256), 0, s, vol, fp, ctx->occ_list, ctx->occ_count,
+                               ctx->tiles, tiles_x, tiles_y, ctx->counters);
+            tiles = ctx->tiles;
+            (void)hipEventRecord(ctx->ring_a[slot], s);   // the ring times the march kernel alone
+        }
         const dim3 replay_grid(2048);  // 8192 waves, one ray each per pass
         if (stats) {
-            hipLaunchKernelGGL((vr::k_march_fast<T, true>), grid, block, 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue, ctx->long_queue, ctx->lane_budget);
+            hipLaunchKernelGGL((vr::k_march_fast<T, true>), grid, block, 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue, ctx->long_queue, ctx->lane_budget, tiles, tiles_x);
             (void)hipEventRecord(ctx->ring_b[slot], s);
             hipLaunchKernelGGL((vr::k_march_long<T, true>), replay_grid, dim3(256), 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue, ctx->long_queue);
             hipLaunchKernelGGL((vr::k_replay_exact<T, true>), replay_grid, dim3(256), 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue);
         } else {
-            hipLaunchKernelGGL((vr::k_march_fast<T, false>), grid, block, 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue, ctx->long_queue, ctx->lane_budget);
+            hipLaunchKernelGGL((vr::k_march_fast<T, false>), grid, block, 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue, ctx->long_queue, ctx->lane_budget, tiles, tiles_x);
             (void)hipEventRecord(ctx->ring_b[slot], s);
             hipLaunchKernelGGL((vr::k_march_long<T, false>), replay_grid, dim3(256), 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue, ctx->long_queue);
             hipLaunchKernelGGL((vr::k_replay_exact<T, false>), replay_grid, dim3(256), 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue);
@@ -365,12 +391,14 @@ int vr_create(int device, vr_ctx **out)
         hipMalloc(&ctx->counters, sizeof(vr::Counters)) != hipSuccess ||
         hipMalloc(&ctx->lut_info, sizeof(vr::LutInfo)) != hipSuccess ||
         hipMalloc(&ctx->occ, 6 * sizeof(int)) != hipSuccess ||
+        hipMalloc(&ctx->d_occ_count, sizeof(uint32_t)) != hipSuccess ||
         hipMemset(ctx->lut, 0, 1024 * sizeof(float)) != hipSuccess ||  // main.cpp:110: zero-initialised table
         hipMemset(ctx->counters, 0, sizeof(vr::Counters)) != hipSuccess ||
         hipMemcpyToSymbol(HIP_SYMBOL(vr::d_phantom), vr::PHANTOM, sizeof(vr::PHANTOM)) != hipSuccess) {
         vr_destroy(ctx);
         return VR_ERR_HIP;
     }
+    if (const char *e = std::getenv("VR_TILE_CLIP")) ctx->tile_clip = std::atoi(e) != 0;
     if (const char *e = std::getenv("VR_LANE_BUDGET")) ctx->lane_budget = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("VR_PARTIAL_BUDGET")) ctx->partial_budget = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("VR_WAVES_PER_BLOCK")) ctx->waves_per_block = std::max(1, std::min(4, std::atoi(e)));
@@ -400,6 +428,8 @@ int vr_destroy(vr_ctx *ctx)
     if (ctx->long_queue) (void)hipFree(ctx->long_queue);
     if (ctx->lut_info) (void)hipFree(ctx->lut_info);
     if (ctx->occ) (void)hipFree(ctx->occ);
+    if (ctx->d_occ_count) (void)hipFree(ctx->d_occ_count);
+    if (ctx->tiles) (void)hipFree(ctx->tiles);
     for (hipEvent_t e : ctx->ring_a)
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->ring_b)
@@ -690,6 +720,17 @@ static int render_impl(vr_ctx *ctx, int width, int height, int x0, int y0, int x
         VR_HIP(ctx, hipMalloc(&ctx->queue, pixels * sizeof(uint32_t)));
         VR_HIP(ctx, hipMalloc(&ctx->long_queue, pixels * sizeof(vr::LongRay)));
         ctx->queue_cap = pixels;
+    }
+    if (fast) {
+        const int tile_px = 1 << vr::kRangeShift;
+        const size_t tile_count = (size_t)((width + tile_px - 1) / tile_px) * (size_t)((height + tile_px - 1) / tile_px);
+        if (tile_count > ctx->tiles_cap) {
+            if (ctx->tiles) (void)hipFree(ctx->tiles);
+            ctx->tiles = nullptr;
+            ctx->tiles_cap = 0;
+            VR_HIP(ctx, hipMalloc(&ctx->tiles, tile_count * sizeof(uint2)));
+            ctx->tiles_cap = tile_count;
+        }
     }
     if (ctx->mode != VR_MODE_REFERENCE_ORDER)
         if (int rc = refresh_occupancy(ctx)) return rc;

@@ -70,6 +70,8 @@ struct Counters {
     unsigned long long replay_rays;
     unsigned int replay_count;  // fast mode: rays queued for the reference-order replay
     unsigned int long_count;    // fast mode: rays handed from the lane march to the wave march
+    unsigned int clip_off;      // fast mode: the per-tile depth ranges could not be built for this camera
+    unsigned int pad0_;
     // everything above is cleared at the start of a frame; what follows persists
     unsigned int lut_error;
     unsigned int pad_;

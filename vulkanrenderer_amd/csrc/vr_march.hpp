@@ -299,6 +299,143 @@ __global__ __launch_bounds__(256) void k_occupied_bounds(const uint32_t *__restr
     }
 }
 
+// ---- depth range of the occupied bricks per 32x32 pixel tile ----------------------------------------
+// Before a frame every occupied brick is projected into the image and widens, for each tile its
+// projection touches, the tile's range [near, far] of distances from the eye.  A ray then only looks
+// at the taps inside its tile's range: rays of tiles no brick touches are finished at once, the others
+// start a few voxels in front of the first occupied brick instead of at the volume's face.
+// Stored per tile as two numbers that only grow, so that a cleared buffer means "nothing":
+// x = 0x7f800000 - bits(near), y = bits(far).  32 pixels: a brick of a 2048^3 volume projects to about
+// that much of a 4K frame, so it touches a handful of tiles (the cost of this pass is its atomics).
+#ifndef VR_RANGE_SHIFT
+#define VR_RANGE_SHIFT 3
+#endif
+constexpr int kRangeShift = VR_RANGE_SHIFT;
+__global__ __launch_bounds__(256) void k_list_occupied(const uint32_t *__restrict__ empty0, uint32_t bricks,
+                                                      uint32_t *__restrict__ list, uint32_t *count)
+{
+    const uint32_t b = blockIdx.x * 256u + threadIdx.x;
+    if (b < bricks && !((empty0[b >> 5] >> (b & 31)) & 1u)) list[atomicAdd(count, 1u)] = b;
+}
+
+// Only bricks a ray can reach first or leave last have something to say.  A ray enters a brick through
+// a face turned towards the eye, out of the brick on the other side of that face; if that neighbour is
+// occupied it is nearer and speaks for the ray.  So a brick widens `near` only if a neighbour across
+// one of its eye-facing faces is empty (or outside the grid), and `far` only if one across a face
+// turned away from the eye is.  That leaves the surface layers: a fraction of the atomics.
+__device__ __forceinline__ bool brick_is_empty(const VolumeView &vol, int bx, int by, int bz)
+{
+    if ((unsigned)bx >= (unsigned)vol.nbx || (unsigned)by >= (unsigned)vol.nby || (unsigned)bz >= (unsigned)vol.nbz) return true;
+    const uint32_t b = (uint32_t)((bz * vol.nby + by) * vol.nbx + bx);
+    return (vol.empty[0][b >> 5] >> (b & 31)) & 1u;
+}
+
+__global__ __launch_bounds__(256) void k_splat_bricks(VolumeView vol, FrameParams fp, const uint32_t *__restrict__ list,
+                                                     uint32_t count, uint2 *__restrict__ tiles, int tiles_x, int tiles_y,
+                                                     Counters *ctr)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t brick = list[i];
+    const int bx = (int)(brick % (uint32_t)vol.nbx), by = (int)((brick / (uint32_t)vol.nbx) % (uint32_t)vol.nby),
+              bz = (int)(brick / (uint32_t)(vol.nbx * vol.nby));
+    // the eye in texel coordinates (inverse of the mapping below)
+    const float eye[3] = {(fp.loc[0] + 0.5f) * vol.fx + 1.5f, (fp.loc[1] + 0.5f) * vol.fy + 1.5f, -fp.loc[2] * vol.fz + 1.5f};
+    const int b3[3] = {bx, by, bz};
+    bool front = false, back = false;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        int lo[3] = {bx, by, bz}, hi[3] = {bx, by, bz};
+        lo[k] -= 1;
+        hi[k] += 1;
+        const bool lo_empty = brick_is_empty(vol, lo[0], lo[1], lo[2]), hi_empty = brick_is_empty(vol, hi[0], hi[1], hi[2]);
+        const float f0 = (float)(b3[k] * kBrick), f1 = f0 + (float)kBrick;
+        if (eye[k] < f0 + 1.0f) {          // the low face is (or may be) turned towards the eye
+            front = front || lo_empty;
+            back = back || hi_empty;
+        }
+        if (eye[k] > f1 - 1.0f) {
+            front = front || hi_empty;
+            back = back || lo_empty;
+        }
+        if (eye[k] >= f0 - 1.0f && eye[k] <= f1 + 1.0f) back = back || lo_empty || hi_empty;   // eye beside the brick: both can be exits
+    }
+    if (!front && !back) return;
+    // Taps whose low corner lies in the brick have texel coordinates G in [8b, 8b + 8) per axis; one
+    // texel more on each side covers the rounding of a tap's position.  G -> world: u = (G - 1.5) / size,
+    // x = u - 0.5, y = v - 0.5, z = -w (VolumeRendering.comp:168,187).
+    const float gx0 = (float)(bx * kBrick - 1), gy0 = (float)(by * kBrick - 1), gz0 = (float)(bz * kBrick - 1);
+    const float ext = (float)(kBrick + 2);
+    const float x0 = (gx0 - 1.5f) / vol.fx - 0.5f, x1 = (gx0 + ext - 1.5f) / vol.fx - 0.5f;
+    const float y0 = (gy0 - 1.5f) / vol.fy - 0.5f, y1 = (gy0 + ext - 1.5f) / vol.fy - 0.5f;
+    const float z0 = -(gz0 - 1.5f) / vol.fz, z1 = -(gz0 + ext - 1.5f) / vol.fz;
+    // pixel of a world point P: px m0 + py m1 + m3 - loc = s (P - loc), solved with Cramer's rule
+    const float m0[3] = {fp.m[0], fp.m[1], fp.m[2]}, m1[3] = {fp.m[4], fp.m[5], fp.m[6]};
+    const float r[3] = {fp.loc[0] - fp.m[12], fp.loc[1] - fp.m[13], fp.loc[2] - fp.m[14]};
+    float pxmin = 3e38f, pxmax = -3e38f, pymin = 3e38f, pymax = -3e38f;
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const float q[3] = {-((k & 1 ? x1 : x0) - fp.loc[0]), -((k & 2 ? y1 : y0) - fp.loc[1]), -((k & 4 ? z1 : z0) - fp.loc[2])};
+        const float c1[3] = {m1[1] * q[2] - m1[2] * q[1], m1[2] * q[0] - m1[0] * q[2], m1[0] * q[1] - m1[1] * q[0]};   // m1 x q
+        const float c2[3] = {r[1] * q[2] - r[2] * q[1], r[2] * q[0] - r[0] * q[2], r[0] * q[1] - r[1] * q[0]};        // r x q
+        const float c3[3] = {m1[1] * r[2] - m1[2] * r[1], m1[2] * r[0] - m1[0] * r[2], m1[0] * r[1] - m1[1] * r[0]};   // m1 x r
+        const float det = m0[0] * c1[0] + m0[1] * c1[1] + m0[2] * c1[2];
+        const float inv = 1.0f / det;
+        const float px = (r[0] * c1[0] + r[1] * c1[1] + r[2] * c1[2]) * inv;
+        const float py = (m0[0] * c2[0] + m0[1] * c2[1] + m0[2] * c2[2]) * inv;
+        const float sc = (m0[0] * c3[0] + m0[1] * c3[1] + m0[2] * c3[2]) * inv;
+        // the corner must lie in front of the eye, well away from it, and project to a finite pixel
+        if (!(sc > 1e-4f) || !(fabsf(px) < 1e7f) || !(fabsf(py) < 1e7f)) ok = false;
+        pxmin = fminf(pxmin, px); pxmax = fmaxf(pxmax, px);
+        pymin = fminf(pymin, py); pymax = fmaxf(pymax, py);
+    }
+    if (!ok) {
+        atomicOr(&ctr->clip_off, 1u);
+        return;
+    }
+    const float cx = 0.5f * (x0 + x1) - fp.loc[0], cy = 0.5f * (y0 + y1) - fp.loc[1], cz = 0.5f * (z0 + z1) - fp.loc[2];
+    const float hx = 0.5f * (x1 - x0), hy = 0.5f * (y1 - y0), hz = 0.5f * (z1 - z0);
+    const float dist = sqrtf(cx * cx + cy * cy + cz * cz), rad = sqrtf(hx * hx + hy * hy + hz * hz) * 1.001f;
+    const float near = fmaxf(dist * 0.99999f - rad, 0.0f), far = dist * 1.00001f + rad;
+    const int tx0 = max(0, (int)floorf(pxmin - 1.5f) >> kRangeShift), tx1 = min(tiles_x - 1, (int)floorf(pxmax + 1.5f) >> kRangeShift);
+    const int ty0 = max(0, (int)floorf(pymin - 1.5f) >> kRangeShift), ty1 = min(tiles_y - 1, (int)floorf(pymax + 1.5f) >> kRangeShift);
+    if (tx0 > tx1 || ty0 > ty1) return;   // off screen
+    if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > 4096) {   // eye very close to a brick: not worth the writes
+        atomicOr(&ctr->clip_off, 1u);
+        return;
+    }
+    const uint32_t nb = 0x7f800000u - __float_as_uint(near), fb = __float_as_uint(far);
+    for (int ty = ty0; ty <= ty1; ty++)
+        for (int tx = tx0; tx <= tx1; tx++) {
+            // both numbers only grow, so a brick that would not raise what the tile already holds has
+            // nothing to write; most bricks lie behind the front-most ones of their tiles, and atomics
+            // on one address are served one after the other
+            uint2 *t = tiles + (size_t)ty * tiles_x + tx;
+            if (front && __atomic_load_n(&t->x, __ATOMIC_RELAXED) < nb) atomicMax(&t->x, nb);
+            if (back && __atomic_load_n(&t->y, __ATOMIC_RELAXED) < fb) atomicMax(&t->y, fb);
+        }
+}
+
+// Narrows a ray's tap range to its tile's depth range.
+__device__ __forceinline__ void clip_to_tile(RayModel &m, const Ray &r, float step, const uint2 *__restrict__ tiles,
+                                             int tiles_x, int px, int py, const Counters *ctr)
+{
+    if (!tiles || ctr->clip_off || !(step > 0.0f)) return;
+    const uint2 range = tiles[(size_t)(py >> kRangeShift) * tiles_x + (px >> kRangeShift)];
+    if (range.y == 0u) {   // no occupied brick projects into this tile
+        m.t_first = 0;
+        m.t_stop = 0x7fffffff;
+        return;
+    }
+    const float near = __uint_as_float(0x7f800000u - range.x), far = __uint_as_float(range.y);
+    const float inv = 1.0f / step;
+    // tap t lies at distance tmax - t * step from the eye (VolumeRendering.comp:185-186); two taps of slack
+    const float first = (r.tmax - near) * inv + 2.0f, stop = (r.tmax - far) * inv - 2.0f;
+    if (first < (float)m.t_first) m.t_first = first < 0.0f ? 0 : (int)first;
+    if (stop > (float)m.t_stop) m.t_stop = (int)fminf(stop, 2e9f);
+}
+
 // Steps (possibly fractional) until the model position leaves [lo, lo + extent) shrunk by the
 // margin along one axis; negative when it is not inside now.  Branch-free on purpose.
 __device__ __forceinline__ float axis_span(float g, float lo, float extent, float inv, float up, float still, float margin)
@@ -660,7 +797,7 @@ struct LongRay {
 // latency-bound chain a single slow ray (one that grazes the object without ever becoming opaque)
 // can keep its wave alive for.
 #ifndef VR_LANE_BUDGET
-#define VR_LANE_BUDGET 160
+#define VR_LANE_BUDGET 128
 #endif
 constexpr int kLaneBudget = VR_LANE_BUDGET;
 #ifndef VR_DECIDE_EVERY
@@ -704,7 +841,8 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
                                             const Decider &dec, uint32_t *__restrict__ out, Counters *ctr,
                                             uint32_t *touched, uint32_t *__restrict__ queue,
                                             LongRay *__restrict__ next_queue, unsigned int *next_count, int budget,
-                                            bool in_rect, int px, int py, uint32_t pixel_id, const LongRay &resume)
+                                            bool in_rect, int px, int py, uint32_t pixel_id, const LongRay &resume,
+                                            const uint2 *__restrict__ tiles, int tiles_x)
 {
 #ifdef VR_DIAG
     const unsigned long long diag_t0 = wall_clock64();
@@ -716,7 +854,8 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
 
     const int last = fp.samples + 1;
     const float step = (r.tmax - r.tmin) / (float)(uint32_t)last;
-    const RayModel rm = ray_model(r, vol, step, -1.0f);
+    RayModel rm = ray_model(r, vol, step, -1.0f);
+    if (in_rect) clip_to_tile(rm, r, step, tiles, tiles_x, px, py, ctr);
 
     double F0 = 0.0, F1 = 0.0, F2 = 0.0, Tr = 1.0;
     float S = 0.0f;
@@ -972,7 +1111,8 @@ template <typename T, bool STATS>
 __global__ __launch_bounds__(256, VR_FAST_MIN_WAVES) void k_march_fast(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
                                                    float4 border, const LutInfo *__restrict__ info,
                                                    uint32_t *__restrict__ out, Counters *ctr, uint32_t *touched,
-                                                   uint32_t *__restrict__ queue, LongRay *__restrict__ long_queue, int budget)
+                                                   uint32_t *__restrict__ queue, LongRay *__restrict__ long_queue, int budget,
+                                                   const uint2 *__restrict__ tiles, int tiles_x)
 {
     __shared__ float4 s_lut[kLutLds];
     stage_lut(s_lut, lut, border);
@@ -981,7 +1121,7 @@ __global__ __launch_bounds__(256, VR_FAST_MIN_WAVES) void k_march_fast(VolumeVie
     uint32_t pixel_id;
     const bool in_rect = lane_pixel(fp, px, py, pixel_id);
     march_lanes<T, STATS, false>(vol, fp, s_lut, dec, out, ctr, touched, queue, long_queue, &ctr->long_count, budget, in_rect, px,
-                                 py, pixel_id, LongRay{});
+                                 py, pixel_id, LongRay{}, tiles, tiles_x);
 }
 
 // What a run of consecutive taps does to the light behind it, taken front to back from full
