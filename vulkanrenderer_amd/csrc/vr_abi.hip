@@ -362,13 +362,13 @@ void launch_frame(vr_ctx *ctx, const vr::FrameParams &fp, uint32_t *d_out, bool 
         if (stats) {
             hipLaunchKernelGGL((vr::k_march_fast<T, true>), grid, block, 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue, ctx->long_queue, ctx->lane_budget, tiles, tiles_x);
             (void)hipEventRecord(ctx->ring_b[slot], s);
-            hipLaunchKernelGGL((vr::k_march_long<T, true>), replay_grid, dim3(256), 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue, ctx->long_queue);
-            hipLaunchKernelGGL((vr::k_replay_exact<T, true>), replay_grid, dim3(256), 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue);
+            hipLaunchKernelGGL((vr::k_march_long<T, true>), replay_grid, dim3(256), 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue, ctx->long_queue, tiles, tiles_x);
+            hipLaunchKernelGGL((vr::k_replay_exact<T, true>), replay_grid, dim3(256), 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue, tiles, tiles_x);
         } else {
             hipLaunchKernelGGL((vr::k_march_fast<T, false>), grid, block, 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue, ctx->long_queue, ctx->lane_budget, tiles, tiles_x);
             (void)hipEventRecord(ctx->ring_b[slot], s);
-            hipLaunchKernelGGL((vr::k_march_long<T, false>), replay_grid, dim3(256), 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue, ctx->long_queue);
-            hipLaunchKernelGGL((vr::k_replay_exact<T, false>), replay_grid, dim3(256), 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue);
+            hipLaunchKernelGGL((vr::k_march_long<T, false>), replay_grid, dim3(256), 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue, ctx->long_queue, tiles, tiles_x);
+            hipLaunchKernelGGL((vr::k_replay_exact<T, false>), replay_grid, dim3(256), 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue, tiles, tiles_x);
         }
     }
 }

@@ -662,7 +662,8 @@ constexpr double kReplayDark = 0x1p-40;
 template <typename T, bool STATS>
 __device__ __forceinline__ void replay_ray(const VolumeView &vol, const FrameParams &fp, const float4 *s_lut,
                                            const Decider &dec, uint32_t *__restrict__ out, Counters *ctr,
-                                           uint32_t *touched, uint32_t out_index)
+                                           uint32_t *touched, uint32_t out_index, const uint2 *__restrict__ tiles,
+                                           int tiles_x)
 {
     const int lane = threadIdx.x & 63;
     int px, py;
@@ -675,7 +676,8 @@ __device__ __forceinline__ void replay_ray(const VolumeView &vol, const FramePar
     // from the eye: where does the ray go dark?
     int start = 0;
     if (dec.ok && r.hit) {
-        const RayModel fm = ray_model(r, vol, step, -1.0f);
+        RayModel fm = ray_model(r, vol, step, -1.0f);
+        clip_to_tile(fm, r, step, tiles, tiles_x, px, py, ctr);
         double tr = 1.0;
         int t = last < fm.t_first ? last : fm.t_first;
         while (t >= fm.t_stop && !(tr < kReplayDark)) {
@@ -704,7 +706,8 @@ __device__ __forceinline__ void replay_ray(const VolumeView &vol, const FramePar
         if (tr < kReplayDark) start = t + 1 > 1 ? t + 1 : 1;   // every tap in front of t + 1 was part of the product
     }
 
-    const RayModel rm = ray_model(r, vol, step, 1.0f);
+    RayModel rm = ray_model(r, vol, step, 1.0f);
+    clip_to_tile(rm, r, step, tiles, tiles_x, px, py, ctr);
     float lo[3] = {0.0f, 0.0f, 0.0f}, hi[3] = {0.0f, 0.0f, 0.0f};
     for (int attempt = 0; attempt < 2; attempt++) {
         if (start > 0) {
@@ -797,7 +800,7 @@ struct LongRay {
 // latency-bound chain a single slow ray (one that grazes the object without ever becoming opaque)
 // can keep its wave alive for.
 #ifndef VR_LANE_BUDGET
-#define VR_LANE_BUDGET 128
+#define VR_LANE_BUDGET 112
 #endif
 constexpr int kLaneBudget = VR_LANE_BUDGET;
 #ifndef VR_DECIDE_EVERY
@@ -1157,7 +1160,7 @@ constexpr int kLongTaps = VR_LONG_TAPS;   // consecutive taps per lane and round
 template <typename T, bool STATS>
 __device__ __forceinline__ bool continue_ray(const VolumeView &vol, const FrameParams &fp, const float4 *s_lut,
                                              const Decider &dec, Counters *ctr, uint32_t *touched, const LongRay &e,
-                                             uint32_t &rgba)
+                                             uint32_t &rgba, const uint2 *__restrict__ tiles, int tiles_x)
 {
     const int lane = threadIdx.x & 63;
     int px, py;
@@ -1165,7 +1168,8 @@ __device__ __forceinline__ bool continue_ray(const VolumeView &vol, const FrameP
     const Ray r = make_ray(fp, px, py);          // identical in every lane
     const int last = fp.samples + 1;
     const float step = (r.tmax - r.tmin) / (float)(uint32_t)last;
-    const RayModel rm = ray_model(r, vol, step, -1.0f);
+    RayModel rm = ray_model(r, vol, step, -1.0f);
+    clip_to_tile(rm, r, step, tiles, tiles_x, px, py, ctr);
     double F0 = e.F0, F1 = e.F1, F2 = e.F2, Tr = e.Tr;
     float S = e.S;
     int t = e.t;
@@ -1266,7 +1270,8 @@ template <typename T, bool STATS>
 __global__ __launch_bounds__(256) void k_march_long(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
                                                    float4 border, const LutInfo *__restrict__ info,
                                                    uint32_t *__restrict__ out, Counters *ctr, uint32_t *touched,
-                                                   uint32_t *__restrict__ queue, const LongRay *__restrict__ long_queue)
+                                                   uint32_t *__restrict__ queue, const LongRay *__restrict__ long_queue,
+                                                   const uint2 *__restrict__ tiles, int tiles_x)
 {
     __shared__ float4 s_lut[kLutLds];
     stage_lut(s_lut, lut, border);
@@ -1277,7 +1282,7 @@ __global__ __launch_bounds__(256) void k_march_long(VolumeView vol, FrameParams 
     for (uint32_t entry = blockIdx.x * 4u + (threadIdx.x >> 6); entry < entries; entry += waves) {
         const LongRay e = long_queue[entry];
         uint32_t rgba;
-        const bool decided = continue_ray<T, STATS>(vol, fp, s_lut, dec, ctr, touched, e, rgba);
+        const bool decided = continue_ray<T, STATS>(vol, fp, s_lut, dec, ctr, touched, e, rgba, tiles, tiles_x);
         if (lane == 0) {
             if (decided) out[e.pixel_id] = rgba;
             else queue[atomicAdd(&ctr->replay_count, 1u)] = e.pixel_id;
@@ -1290,7 +1295,8 @@ template <typename T, bool STATS>
 __global__ __launch_bounds__(256) void k_replay_exact(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
                                                      float4 border, const LutInfo *__restrict__ info,
                                                      uint32_t *__restrict__ out, Counters *ctr, uint32_t *touched,
-                                                     const uint32_t *__restrict__ queue)
+                                                     const uint32_t *__restrict__ queue, const uint2 *__restrict__ tiles,
+                                                     int tiles_x)
 {
     __shared__ float4 s_lut[kLutLds];
     stage_lut(s_lut, lut, border);
@@ -1298,7 +1304,7 @@ __global__ __launch_bounds__(256) void k_replay_exact(VolumeView vol, FrameParam
     const uint32_t waves = gridDim.x * 4u;
     const uint32_t entries = ctr->replay_count;
     for (uint32_t entry = blockIdx.x * 4u + (threadIdx.x >> 6); entry < entries; entry += waves)
-        replay_ray<T, STATS>(vol, fp, s_lut, dec, out, ctr, touched, queue[entry]);
+        replay_ray<T, STATS>(vol, fp, s_lut, dec, out, ctr, touched, queue[entry], tiles, tiles_x);
 }
 
 // Rays of the rectangle that hit the box (the reference marches samples + 2 taps on each).
