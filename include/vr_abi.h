@@ -89,6 +89,12 @@ int vr_volume_info(const vr_ctx *ctx, int *nx, int *ny, int *nz, int *dtype, flo
  * main.cpp:39), written to a host buffer of nx*ny*nz floats.  For checks. */
 int vr_read_volume_normalized(vr_ctx *ctx, float *out);
 
+/* prepareHistogramVolumeData, main.cpp:166-181: the 100-bin histogram of the normalised voxels the
+ * transfer-function editor draws behind its control graphs (bin i counts the values in
+ * [i/100, (i + 0.9)/100], all bins divided by the largest count).  The voxel values are counted on
+ * the GPU; out receives 100 floats. */
+int vr_histogram(vr_ctx *ctx, float out[100]);
+
 /* updateTransferFunction, main.cpp:643-686, plus the upload of the table, main.cpp:687-736.
  * points[c] / counts[c]: control graph of channel c (R,G,B,A), sorted by x.  The table lives on
  * the GPU and persists between calls exactly like `transferFunction` (main.cpp:110); entries no

@@ -20,7 +20,7 @@ MODE_REFERENCE_ORDER, MODE_FAST, MODE_REFERENCE_SKIP = 0, 1, 2
 ABI_SYMBOLS = (
     "vr_create", "vr_destroy", "vr_last_error", "vr_stream", "vr_synchronize",
     "vr_upload_volume", "vr_upload_volume_device", "vr_load_volume_slices", "vr_volume_info",
-    "vr_read_volume_normalized", "vr_set_transfer_function", "vr_get_lut",
+    "vr_read_volume_normalized", "vr_histogram", "vr_set_transfer_function", "vr_get_lut",
     "vr_control_point_intensity", "vr_set_camera", "vr_set_camera_raw", "vr_get_camera",
     "vr_camera_uniforms",
     "vr_set_sampling", "vr_set_mode", "vr_render", "vr_render_rect", "vr_render_bands",
@@ -84,6 +84,7 @@ def lib():
     L.vr_load_volume_slices.argtypes = [vp, C.c_char_p]
     L.vr_volume_info.argtypes = [vp] + [C.POINTER(C.c_int)] * 4 + [fp]
     L.vr_read_volume_normalized.argtypes = [vp, fp]
+    L.vr_histogram.argtypes = [vp, fp]
     L.vr_set_transfer_function.argtypes = [vp, C.POINTER(C.POINTER(CtrlPt)), C.POINTER(C.c_int), C.c_int]
     L.vr_get_lut.argtypes = [vp, fp]
     L.vr_control_point_intensity.argtypes = [C.c_float, C.c_float]
@@ -236,6 +237,12 @@ class VolumeRenderer:
         i = self.volume_info()
         out = np.empty((i["nz"], i["ny"], i["nx"]), np.float32)
         self._check(lib().vr_read_volume_normalized(self._h, _fp(out)))
+        return out
+
+    def prepare_histogram_volume_data(self):
+        """The 100-bin intensity histogram of main.cpp:166-181."""
+        out = np.empty(100, np.float32)
+        self._check(lib().vr_histogram(self._h, _fp(out)))
         return out
 
     def phantom_generate_device(self, ptr, dtype_bytes, n, seed=0x5EED1234):

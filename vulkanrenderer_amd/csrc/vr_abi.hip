@@ -554,6 +554,53 @@ int vr_read_volume_normalized(vr_ctx *ctx, float *out)
     return VR_OK;
 }
 
+int vr_histogram(vr_ctx *ctx, float out[100])
+{
+    if (!ctx || !out) return fail(ctx, VR_ERR_ARG, "null argument");
+    if (!ctx->bricks) return fail(ctx, VR_ERR_STATE, "no volume uploaded");
+    if (ctx->sub) return fail(ctx, VR_ERR_STATE, "the context holds a sub-volume");
+    if (int rc = bind(ctx)) return rc;
+    const size_t bins = 65536;
+    unsigned long long *d_hist = nullptr;
+    VR_HIP(ctx, hipMalloc(&d_hist, bins * sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d_hist, 0, bins * sizeof(unsigned long long), ctx->stream);
+    const unsigned blocks = (unsigned)std::min<size_t>((ctx->brick_count * 64 + 255) / 256, 256 * 64);
+    if (ctx->dtype == VR_DTYPE_U8)
+        hipLaunchKernelGGL((vr::k_value_histogram<uint8_t>), dim3(blocks), dim3(256), 0, ctx->stream, view_of(ctx), d_hist);
+    else
+        hipLaunchKernelGGL((vr::k_value_histogram<uint16_t>), dim3(blocks), dim3(256), 0, ctx->stream, view_of(ctx), d_hist);
+    std::vector<unsigned long long> counts(bins);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(counts.data(), d_hist, bins * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_hist);
+    if (e != hipSuccess) return fail(ctx, VR_ERR_HIP, hipGetErrorString(e));
+
+    // main.cpp:166-181 on the sorted normalised values, which are runs of float(v)/float(max), v ascending:
+    // lower_bound(x) = number of values < x, upper_bound(x) = number of values <= x
+    const float mx = ctx->max_value;
+    const int top = (int)mx;
+    std::vector<unsigned long long> below(top + 2, 0);   // below[v] = voxels with a value < v
+    for (int v = 0; v <= top; v++) below[v + 1] = below[v] + counts[v];
+    const float step = 1.0f / 100;                        // main.cpp:170
+    size_t count_max = 0;
+    for (int i = 0; i < 100; i++) {
+        const float lo = step * (float)i;                  // main.cpp:174, float
+        const double hi = (double)step * ((double)i + 0.9);   // main.cpp:175, double
+        int a = 0, b = top + 1;                            // first v with !(float(v)/max < lo)
+        while (a < b) { const int m = (a + b) / 2; if ((float)m / mx < lo) a = m + 1; else b = m; }
+        const long long lower = (long long)below[a];
+        a = 0; b = top + 1;                                // first v with hi < float(v)/max
+        while (a < b) { const int m = (a + b) / 2; if (!(hi < (double)((float)m / mx))) a = m + 1; else b = m; }
+        const long long upper = (long long)below[a];
+        const float c = (float)(upper - lower);            // main.cpp:176
+        out[i] = c;
+        if (c > (float)count_max) count_max = (size_t)c;   // main.cpp:178
+    }
+    for (int i = 0; i < 100; i++) out[i] /= (float)count_max;   // main.cpp:180
+    return VR_OK;
+}
+
 int vr_set_transfer_function(vr_ctx *ctx, const vr_ctrl_pt *const points[4], const int counts[4], int reset_state)
 {
     if (!ctx || !points || !counts) return fail(ctx, VR_ERR_ARG, "null argument");

@@ -444,6 +444,47 @@ __global__ __launch_bounds__(256) void k_read_normalized(VolumeView vol, float *
     }
 }
 
+// ---- intensity histogram ---------------------------------------------------------------------
+// Counts of the raw voxel values (65536 bins), from which the host derives the reference's 100-bin
+// histogram (prepareHistogramVolumeData, main.cpp:166-181: float(v)/float(max) is monotone in v, so
+// its sorted-array bounds are sums of these counts).  One thread per x-row of 8 cells of a brick,
+// apron and padding left out so that every voxel counts once; equal neighbours are added together
+// and zeros, the background of most volumes, are summed per wave first.
+template <typename T>
+__global__ __launch_bounds__(256) void k_value_histogram(VolumeView vol, unsigned long long *__restrict__ hist)
+{
+    const uint64_t rows = (uint64_t)vol.nbx * vol.nby * vol.nbz * 64u;
+    unsigned long long zeros = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t brick = i >> 6;
+        const int ly = (int)(i & 7), lz = (int)((i >> 3) & 7);
+        const int bx = (int)(brick % (uint64_t)vol.nbx), by = (int)((brick / (uint64_t)vol.nbx) % (uint64_t)vol.nby),
+                  bz = (int)(brick / ((uint64_t)vol.nbx * vol.nby));
+        const int iy = by * kBrick + ly - kPad, iz = bz * kBrick + lz - kPad;
+        if ((unsigned)iy >= (unsigned)vol.ny || (unsigned)iz >= (unsigned)vol.nz) continue;
+        const T *row = (const T *)vol.bricks + brick * kBrickElems + (lz * kRow + ly) * kRow;
+        uint32_t run_value = 0, run = 0;
+        for (int lx = 0; lx < kBrick; lx++) {
+            const int ix = bx * kBrick + lx - kPad;
+            if ((unsigned)ix >= (unsigned)vol.nx) continue;
+            const uint32_t v = row[lx];
+            if (v == 0u) {
+                zeros++;
+                continue;
+            }
+            if (v != run_value) {
+                if (run) atomicAdd(&hist[run_value], (unsigned long long)run);
+                run_value = v;
+                run = 0;
+            }
+            run++;
+        }
+        if (run) atomicAdd(&hist[run_value], (unsigned long long)run);
+    }
+    for (int o = 32; o > 0; o >>= 1) zeros += __shfl_xor(zeros, o);
+    if ((threadIdx.x & 63) == 0 && zeros) atomicAdd(&hist[0], zeros);
+}
+
 // ---- synthetic phantom ------------------------------------------------------------------------
 // 3-D Shepp-Logan head (ten ellipsoids, contrast in tenths so the sum is an exact integer),
 // voxel centres of [-1,1]^3, small hash noise inside the outer ellipsoid, exactly 0 outside it.
