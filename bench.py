@@ -112,16 +112,23 @@ def main():
     sf = SortFirstFrame(w, h, rank, world, device)
     lib_stream = torch.cuda.ExternalStream(ctx.stream, device=device)
     target = sf.frame if world == 1 else sf.local
+    gathered = [None, None]      # per band buffer: event after the gather that last read it
 
     def frame(step):
         ctx.set_camera(*orbit_camera(step))
         if world == 1:
             ctx.render_bands(w, h, 0, 1, ptr=target.data_ptr())
             return
-        lib_stream.wait_stream(torch.cuda.current_stream())          # last gather has read `local`
-        ctx.render_bands(w, h, rank, world, ptr=target.data_ptr())
+        # two band buffers in turn: this frame is rendered while the previous one is still in the gather
+        turn = sf.turn
+        if gathered[turn] is not None:
+            lib_stream.wait_event(gathered[turn])
+        ctx.render_bands(w, h, rank, world, ptr=sf.local.data_ptr())
         torch.cuda.current_stream().wait_stream(lib_stream)
         sf.exchange()
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        gathered[turn] = ev
 
     def fence():
         ctx.synchronize()
@@ -156,7 +163,8 @@ def main():
     agg = {"algorithmic_bytes": 0, "samples_evaluated": 0, "bricks_touched": 0, "replay_rays": 0, "rays_hit": 0}
     for s in stats_steps:
         ctx.set_camera(*orbit_camera(s))
-        st = ctx.render_bands(w, h, rank if world > 1 else 0, world if world > 1 else 1, ptr=target.data_ptr(), stats=True)
+        st = ctx.render_bands(w, h, rank if world > 1 else 0, world if world > 1 else 1,
+                              ptr=(target if world == 1 else sf.local).data_ptr(), stats=True)
         for k in agg:
             agg[k] += st[k]
     ctx.synchronize()

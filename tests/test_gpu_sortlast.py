@@ -136,7 +136,8 @@ def test_boxes_assemble_the_single_context_frame(vr, torch, oracle, dtype, n, gr
             for r in range(len(ctxs)):
                 lo, hi = sl.brick_box(bricks, grid, sl.box_of_rank(r, grid))
                 ref = oracle.render_partial(vol, lut, vp[4:8], m, w, h, 90, lo, hi)
-                assert np.allclose(parts[r], ref, rtol=2e-6, atol=1e-7), (cname, r, np.abs(parts[r] - ref).max())
+                # a box drops a ray once its own taps made it darker than 2^-20; where exactly differs by a few taps
+                assert np.allclose(parts[r], ref, rtol=2e-6, atol=3e-6), (cname, r, np.abs(parts[r] - ref).max())
             assert np.all(merged[:, 3] <= 2.0 ** -20)    # every hit ray reached its back tap's owner or went dark
     finally:
         for c in ctxs:

@@ -17,6 +17,7 @@ ap.add_argument("--width", type=int, default=3840)
 ap.add_argument("--height", type=int, default=2160)
 ap.add_argument("--frames", type=int, default=4)
 ap.add_argument("--mode", type=int, default=1)
+ap.add_argument("--parts", type=int, default=1, help="render only sort-first part 0 of this many")
 a = ap.parse_args()
 n = a.volume
 ctx = vr.VolumeRenderer(0)
@@ -33,7 +34,10 @@ out = torch.empty(a.width * a.height * 4, dtype=torch.uint8, device="cuda")
 torch.cuda.synchronize()
 for i in range(a.frames):
     ctx.set_camera(*bench.orbit_camera(i * 30))
-    ctx.render_device(a.width, a.height, out.data_ptr())
+    if a.parts > 1:
+        ctx.render_bands(a.width, a.height, 0, a.parts, ptr=out.data_ptr())
+    else:
+        ctx.render_device(a.width, a.height, out.data_ptr())
 ctx.synchronize()
 print("ms", ctx.march_kernel_times(a.frames))
 ctx.close()

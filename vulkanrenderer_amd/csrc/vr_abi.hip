@@ -68,10 +68,9 @@ struct vr_ctx {
     // memory round trips (fetch rounds + passes of the skipping loop) a lane spends on a ray before a
     // wave takes the ray over
     int lane_budget = vr::kLaneBudget;
-    // Fetch rounds of the sort-last lane march before a wave takes a ray over.  Boxes cannot stop a ray
-    // as early as the whole-volume march (they do not know what lies in front), so most rays need
-    // several hundred taps and only extreme ones are worth a wave of their own.
-    int partial_budget = 4096;
+    // The same for the sort-last lane march.  Boxes cannot stop a ray as early as the whole-volume march
+    // (they do not know what lies in front), so their rays need more taps.
+    int partial_budget = 96;
     int samples = 200;  // VolumeRendering.comp:173
     int mode = VR_MODE_REFERENCE_ORDER;
 
@@ -1011,12 +1010,30 @@ int vr_render_partial(vr_ctx *ctx, int width, int height, float *out, int out_is
     const float4 border = make_float4(ctx->border[0], ctx->border[1], ctx->border[2], ctx->border[3]);
     const float4 *lut = reinterpret_cast<const float4 *>(ctx->lut);
     const dim3 long_grid(2048);
+    // depth range of this box's surface bricks per tile, as in the whole-volume fast mode
+    const int tile_px = 1 << vr::kRangeShift;
+    const int tiles_x = (width + tile_px - 1) / tile_px, tiles_y = (height + tile_px - 1) / tile_px;
+    const size_t tile_count = (size_t)tiles_x * tiles_y;
+    if (tile_count > ctx->tiles_cap) {
+        if (ctx->tiles) (void)hipFree(ctx->tiles);
+        ctx->tiles = nullptr;
+        ctx->tiles_cap = 0;
+        VR_HIP(ctx, hipMalloc(&ctx->tiles, tile_count * sizeof(uint2)));
+        ctx->tiles_cap = tile_count;
+    }
+    const uint2 *range = nullptr;
+    if (ctx->tile_clip && ctx->occ_count > 0) {
+        VR_HIP(ctx, hipMemsetAsync(ctx->tiles, 0, tile_count * sizeof(uint2), ctx->stream));
+        hipLaunchKernelGGL(vr::k_splat_bricks, dim3((ctx->occ_count + 255) / 256), dim3(256), 0, ctx->stream, vol, fp, ctx->occ_list,
+                           ctx->occ_count, ctx->tiles, tiles_x, tiles_y, ctx->counters);
+        range = ctx->tiles;
+    }
     if (ctx->dtype == VR_DTYPE_U8) {
-        hipLaunchKernelGGL((vr::k_march_partial<uint8_t>), dim3((unsigned)tiles), dim3(64), 0, ctx->stream, vol, fp, lut, border, d_out, ctx->counters, ctx->long_queue, ctx->partial_budget);
-        hipLaunchKernelGGL((vr::k_partial_long<uint8_t>), long_grid, dim3(256), 0, ctx->stream, vol, fp, lut, border, d_out, ctx->counters, ctx->long_queue);
+        hipLaunchKernelGGL((vr::k_march_partial<uint8_t>), dim3((unsigned)tiles), dim3(64), 0, ctx->stream, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->long_queue, ctx->partial_budget, range, tiles_x);
+        hipLaunchKernelGGL((vr::k_partial_long<uint8_t>), long_grid, dim3(256), 0, ctx->stream, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->long_queue, range, tiles_x);
     } else {
-        hipLaunchKernelGGL((vr::k_march_partial<uint16_t>), dim3((unsigned)tiles), dim3(64), 0, ctx->stream, vol, fp, lut, border, d_out, ctx->counters, ctx->long_queue, ctx->partial_budget);
-        hipLaunchKernelGGL((vr::k_partial_long<uint16_t>), long_grid, dim3(256), 0, ctx->stream, vol, fp, lut, border, d_out, ctx->counters, ctx->long_queue);
+        hipLaunchKernelGGL((vr::k_march_partial<uint16_t>), dim3((unsigned)tiles), dim3(64), 0, ctx->stream, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->long_queue, ctx->partial_budget, range, tiles_x);
+        hipLaunchKernelGGL((vr::k_partial_long<uint16_t>), long_grid, dim3(256), 0, ctx->stream, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->long_queue, range, tiles_x);
     }
     VR_HIP(ctx, hipGetLastError());
     if (!out_is_device) {

@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void k_splat_bricks(VolumeView vol, FrameParam
               bz = (int)(brick / (uint32_t)(vol.nbx * vol.nby));
     // the eye in texel coordinates (inverse of the mapping below)
     const float eye[3] = {(fp.loc[0] + 0.5f) * vol.fx + 1.5f, (fp.loc[1] + 0.5f) * vol.fy + 1.5f, -fp.loc[2] * vol.fz + 1.5f};
-    const int b3[3] = {bx, by, bz};
+    const int b3[3] = {bx, by, bz}, org[3] = {vol.ox, vol.oy, vol.oz};
     bool front = false, back = false;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void k_splat_bricks(VolumeView vol, FrameParam
         lo[k] -= 1;
         hi[k] += 1;
         const bool lo_empty = brick_is_empty(vol, lo[0], lo[1], lo[2]), hi_empty = brick_is_empty(vol, hi[0], hi[1], hi[2]);
-        const float f0 = (float)(b3[k] * kBrick), f1 = f0 + (float)kBrick;
+        const float f0 = (float)(b3[k] * kBrick + org[k]), f1 = f0 + (float)kBrick;
         if (eye[k] < f0 + 1.0f) {          // the low face is (or may be) turned towards the eye
             front = front || lo_empty;
             back = back || hi_empty;
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(256) void k_splat_bricks(VolumeView vol, FrameParam
     // Taps whose low corner lies in the brick have texel coordinates G in [8b, 8b + 8) per axis; one
     // texel more on each side covers the rounding of a tap's position.  G -> world: u = (G - 1.5) / size,
     // x = u - 0.5, y = v - 0.5, z = -w (VolumeRendering.comp:168,187).
-    const float gx0 = (float)(bx * kBrick - 1), gy0 = (float)(by * kBrick - 1), gz0 = (float)(bz * kBrick - 1);
+    const float gx0 = (float)(bx * kBrick + vol.ox - 1), gy0 = (float)(by * kBrick + vol.oy - 1), gz0 = (float)(bz * kBrick + vol.oz - 1);
     const float ext = (float)(kBrick + 2);
     const float x0 = (gx0 - 1.5f) / vol.fx - 0.5f, x1 = (gx0 + ext - 1.5f) / vol.fx - 0.5f;
     const float y0 = (gy0 - 1.5f) / vol.fy - 0.5f, y1 = (gy0 + ext - 1.5f) / vol.fy - 0.5f;
@@ -406,8 +406,17 @@ __global__ __launch_bounds__(256) void k_splat_bricks(VolumeView vol, FrameParam
         return;
     }
     const uint32_t nb = 0x7f800000u - __float_as_uint(near), fb = __float_as_uint(far);
-    for (int ty = ty0; ty <= ty1; ty++)
+    for (int ty = ty0; ty <= ty1; ty++) {
+        // only tiles this launch renders: inside the rectangle and, with a sort-first split, in one of
+        // this part's 16-row bands
+        const int r0 = (ty << kRangeShift) - fp.y0, r1 = r0 + (1 << kRangeShift) - 1;   // rectangle rows of the tile
+        if (r1 < 0 || r0 >= fp.y1 - fp.y0) continue;
+        const int band0 = (r0 < 0 ? 0 : r0) >> 4, band1 = r1 >> 4;
+        bool mine = false;
+        for (int b = band0; b <= band1; b++) mine = mine || (b % fp.parts == fp.part);
+        if (!mine) continue;
         for (int tx = tx0; tx <= tx1; tx++) {
+            if (((tx + 1) << kRangeShift) <= fp.x0 || (tx << kRangeShift) >= fp.x1) continue;
             // both numbers only grow, so a brick that would not raise what the tile already holds has
             // nothing to write; most bricks lie behind the front-most ones of their tiles, and atomics
             // on one address are served one after the other
@@ -415,6 +424,7 @@ __global__ __launch_bounds__(256) void k_splat_bricks(VolumeView vol, FrameParam
             if (front && __atomic_load_n(&t->x, __ATOMIC_RELAXED) < nb) atomicMax(&t->x, nb);
             if (back && __atomic_load_n(&t->y, __ATOMIC_RELAXED) < fb) atomicMax(&t->y, fb);
         }
+    }
 }
 
 // Narrows a ray's tap range to its tile's depth range.
@@ -820,6 +830,50 @@ constexpr int kClearRun = VR_CLEAR_RUN;   // transparent taps in a row that end 
 #endif
 constexpr int kTapGroup = VR_TAP_GROUP;   // taps a lane inside material fetches per round
 
+// ---- pieces shared with the sort-last path (vr_sortlast.hpp) ------------------------------------------
+// There a context holds one box of the volume's bricks and marches only the taps whose filter
+// footprint starts in that box; per pixel it produces kPartial floats (F0, F1, F2, Tr, S).
+constexpr int kPartial = 5;             // floats per pixel of a partial result
+// A box stops marching a ray once the transmittance of its own taps is below this: what it leaves
+// out changes the ray's colour by at most 2 * kTrCut * (largest colour), which k_decide_partials
+// adds to its error interval.
+constexpr double kTrCut = 0x1p-20;
+
+// Cell of a tap in the coordinates of this context's brick box; false when another box owns the tap.
+__device__ __forceinline__ bool tap_cell_local(const Tap &p, const VolumeView &v, Cell &c)
+{
+    c = tap_cell(p, v);
+    c.sx -= v.ox;
+    c.sy -= v.oy;
+    c.sz -= v.oz;
+    return (unsigned)c.sx < (unsigned)(v.nbx * kBrick) && (unsigned)c.sy < (unsigned)(v.nby * kBrick) &&
+           (unsigned)c.sz < (unsigned)(v.nbz * kBrick);
+}
+
+// Writes a ray's partial result; adds the back-most tap first when the box owns it.
+template <typename T>
+__device__ __forceinline__ void finish_partial(const VolumeView &vol, const Ray &r, float step, const float4 *s_lut,
+                                               double F0, double F1, double F2, double Tr, float S, float *o)
+{
+    if (!(Tr < kTrCut)) {
+        // back-most tap, if it is this box's: its colour enters unweighted (VolumeRendering.comp:189-191)
+        const Tap p = tap_position(r, vol, step, 0);
+        Cell c;
+        if (tap_cell_local(p, vol, c)) {
+            const float4 tf = sample_tf(s_lut, sample_volume<T>(c, brick_of(c, vol), vol));
+            F0 = __builtin_fma(Tr, (double)tf.x, F0);
+            F1 = __builtin_fma(Tr, (double)tf.y, F1);
+            F2 = __builtin_fma(Tr, (double)tf.z, F2);
+            Tr = 0.0;
+        }
+    }
+    o[0] = (float)F0;
+    o[1] = (float)F1;
+    o[2] = (float)F2;
+    o[3] = (float)Tr;
+    o[4] = S;
+}
+
 // ---- front-to-back march ------------------------------------------------------------------------
 // Visits the taps from the eye towards the back, steps over empty cubes of the occupancy pyramid,
 // and stops a ray as soon as its RGBA8 value is decided.
@@ -839,12 +893,12 @@ constexpr int kTapGroup = VR_TAP_GROUP;   // taps a lane inside material fetches
 // empty space (cheap, divergent), then all lanes that found a tap fetch it together.
 //
 // One lane marches one ray; the 64 rays of a wave are the pixels of an 8x8 tile.
-template <typename T, bool STATS, bool RESUME>
+template <typename T, bool STATS, bool PARTIAL>
 __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FrameParams &fp, const float4 *s_lut,
                                             const Decider &dec, uint32_t *__restrict__ out, Counters *ctr,
                                             uint32_t *touched, uint32_t *__restrict__ queue,
                                             LongRay *__restrict__ next_queue, unsigned int *next_count, int budget,
-                                            bool in_rect, int px, int py, uint32_t pixel_id, const LongRay &resume,
+                                            bool in_rect, int px, int py, uint32_t pixel_id, float *__restrict__ partial_out,
                                             const uint2 *__restrict__ tiles, int tiles_x)
 {
 #ifdef VR_DIAG
@@ -863,11 +917,6 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
     double F0 = 0.0, F1 = 0.0, F2 = 0.0, Tr = 1.0;
     float S = 0.0f;
     int t = last < rm.t_first ? last : rm.t_first;   // front-most tap that can matter
-    if (RESUME) {
-        F0 = resume.F0; F1 = resume.F1; F2 = resume.F2; Tr = resume.Tr;
-        S = resume.S;
-        t = resume.t < t ? resume.t : t;
-    }
     const int t_stop = rm.t_stop;       // taps below it (the back tap aside) cannot matter either
     bool marching = in_rect && r.hit;   // still has taps with index >= 1 to visit
     bool decided = false;
@@ -878,7 +927,7 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
 
     uint32_t solid = 0xffffffffu;       // last brick found occupied: its taps need no pyramid lookup
     unsigned long long solid_mask = 0;  // and its 2^3-cell block bits
-    bool in_air = !RESUME;              // the last tap looked at was in an empty cube: the line model leads
+    bool in_air = true;                 // the last tap looked at was in an empty cube: the line model leads
     // The last tap fetched had alpha != 0 (or only one transparent tap since): the next tap is fetched
     // without asking the occupancy tables.  Any tap may be fetched, so this is only a bet that saves the
     // look-ups while a ray is inside material; two transparent taps in a row end it.
@@ -915,6 +964,18 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
                     bricks[k] = brick_of(cs[k], vol);
                 }
                 have = true;
+                if (PARTIAL) {
+                    // sort-last: the tap may be another box's (one tap per round there)
+                    static_assert(!PARTIAL || kTapGroup == 1, "the ownership test looks at one tap");
+                    if (!tap_cell_local(tap_position(r, vol, step, t), vol, cs[0])) {
+                        have = false;
+                        taps = 0;
+                        material = false;
+                        in_air = false;
+                    } else {
+                        bricks[0] = brick_of(cs[0], vol);
+                    }
+                }
             }
         }
         // 1. lanes outside material step over empty space until they stand on a tap that must be
@@ -939,7 +1000,16 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
 #ifdef VR_DIAG
                 diag_exact++;
 #endif
-                c = tap_cell(tap_position(r, vol, step, t), vol);
+                if (PARTIAL) {
+                    if (!tap_cell_local(tap_position(r, vol, step, t), vol, c)) {
+                        // another box's tap (only near the faces of this one): nothing to do with it
+                        t -= 1;
+                        in_air = true;
+                        continue;
+                    }
+                } else {
+                    c = tap_cell(tap_position(r, vol, step, t), vol);
+                }
             }
             brick = brick_of(c, vol);
             int level = -1;
@@ -1027,6 +1097,7 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
                     Tr = Tr * (1.0 - a);
                     material = kMaterialBet;
                     clear_run = 0;
+                    if (PARTIAL && Tr < kTrCut) marching = false;   // dark: whatever follows in this box cannot matter
                 } else if (material) {
                     clear_run++;
                     if (clear_run >= kClearRun) {
@@ -1039,7 +1110,7 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
         }
         // 3. early termination, tested every few rounds for all lanes at once: the test costs about as
         //    much as half a tap and the whole wave pays for it whenever a single lane runs it
-        if ((round & (kDecideEvery - 1)) == kDecideEvery - 1 && fast_ok && marching && Tr < 0.03125) {
+        if (!PARTIAL && (round & (kDecideEvery - 1)) == kDecideEvery - 1 && fast_ok && marching && Tr < 0.03125) {
             if (try_decide(t + 1)) {     // taps t .. 0 are still to come
                 decided = true;
                 marching = false;
@@ -1056,6 +1127,12 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
         e.pixel_id = pixel_id; e.t = t; e.S = S; e.pad_ = 0.0f;
         e.F0 = F0; e.F1 = F1; e.F2 = F2; e.Tr = Tr;
         next_queue[atomicAdd(next_count, 1u)] = e;
+    } else if (PARTIAL) {
+        if (in_rect) {
+            float *o = partial_out + (size_t)pixel_id * kPartial;
+            if (r.hit) finish_partial<T>(vol, r, step, s_lut, F0, F1, F2, Tr, S, o);
+            else o[0] = o[1] = o[2] = o[3] = o[4] = 0.0f;
+        }
     } else if (in_rect) {
         if (r.hit && !decided) {
             // back-most tap: its colour enters unweighted by its alpha (VolumeRendering.comp:189-191)
@@ -1077,7 +1154,7 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
         if (!r.hit || decided) out[pixel_id] = rgba;
     }
     if (STATS && in_rect) {
-        if (!RESUME) atomicAdd(&ctr->rays_hit, r.hit ? 1ull : 0ull);
+        atomicAdd(&ctr->rays_hit, r.hit ? 1ull : 0ull);
         atomicAdd(&ctr->samples_evaluated, evaluated);
         atomicAdd(&ctr->cells_read, lookups);
     }
@@ -1090,7 +1167,7 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
         diag_both = max(diag_both, (unsigned int)__shfl_xor((int)diag_both, o));
         diag_sum += (unsigned int)__shfl_xor((int)diag_sum, o);
     }
-    if (g_vr_timeline && !RESUME && (threadIdx.x & 63) == 0) {
+    if (g_vr_timeline && !PARTIAL && (threadIdx.x & 63) == 0) {
         const unsigned long long wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
         unsigned int hw;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -1124,7 +1201,7 @@ __global__ __launch_bounds__(256, VR_FAST_MIN_WAVES) void k_march_fast(VolumeVie
     uint32_t pixel_id;
     const bool in_rect = lane_pixel(fp, px, py, pixel_id);
     march_lanes<T, STATS, false>(vol, fp, s_lut, dec, out, ctr, touched, queue, long_queue, &ctr->long_count, budget, in_rect, px,
-                                 py, pixel_id, LongRay{}, tiles, tiles_x);
+                                 py, pixel_id, nullptr, tiles, tiles_x);
 }
 
 // What a run of consecutive taps does to the light behind it, taken front to back from full
@@ -1157,10 +1234,13 @@ constexpr int kLongTaps = VR_LONG_TAPS;   // consecutive taps per lane and round
 // consecutive taps at once (or the whole wave steps over an empty cube), then the taps with a
 // non-zero alpha are blended front to back in tap order, the accumulation k_march_fast does one tap
 // at a time; the decision test runs once per 64 taps.  Returns whether the bytes are decided.
-template <typename T, bool STATS>
+// With PARTIAL (sort-last) only the taps of this context's box are taken, nothing is decided, the
+// march stops once the box's own taps have made the ray dark, and the sums go to partial_out.
+template <typename T, bool STATS, bool PARTIAL = false>
 __device__ __forceinline__ bool continue_ray(const VolumeView &vol, const FrameParams &fp, const float4 *s_lut,
                                              const Decider &dec, Counters *ctr, uint32_t *touched, const LongRay &e,
-                                             uint32_t &rgba, const uint2 *__restrict__ tiles, int tiles_x)
+                                             uint32_t &rgba, const uint2 *__restrict__ tiles, int tiles_x,
+                                             float *__restrict__ partial_out = nullptr)
 {
     const int lane = threadIdx.x & 63;
     int px, py;
@@ -1177,7 +1257,7 @@ __device__ __forceinline__ bool continue_ray(const VolumeView &vol, const FrameP
     rgba = 0xff000000u;
     unsigned long long evaluated = 0;
     if (t > rm.t_first) t = rm.t_first;
-    while (t >= rm.t_stop && !decided) {
+    while (t >= rm.t_stop && !decided && !(PARTIAL && Tr < kTrCut)) {
         const int n = empty_span(vol, rm, t);   // wave-uniform
         if (n > 0) {
             t -= n;
@@ -1191,7 +1271,12 @@ __device__ __forceinline__ bool continue_ray(const VolumeView &vol, const FrameP
         for (int k = 0; k < kLongTaps; k++) {
             const int tt = t - (lane * kLongTaps + k);
             fetch[k] = tt >= rm.t_stop;
-            cs[k] = tap_cell(tap_position(r, vol, step, fetch[k] ? tt : rm.t_stop), vol);
+            if (PARTIAL) {
+                if (!tap_cell_local(tap_position(r, vol, step, fetch[k] ? tt : rm.t_stop), vol, cs[k])) fetch[k] = false;
+                if (!fetch[k]) cs[k].sx = cs[k].sy = cs[k].sz = 0;   // any cell of the box: never fetched
+            } else {
+                cs[k] = tap_cell(tap_position(r, vol, step, fetch[k] ? tt : rm.t_stop), vol);
+            }
             bricks[k] = brick_of(cs[k], vol);
         }
 #pragma unroll
@@ -1243,7 +1328,16 @@ __device__ __forceinline__ bool continue_ray(const VolumeView &vol, const FrameP
             Tr = Tr * part.tr;
         }
         t -= 64 * kLongTaps;
-        if (dec.ok && Tr < 0.03125) decided = dec.decide(F0, F1, F2, Tr, S, (t > 0 ? t : 0) + 1, rgba);
+        if (!PARTIAL && dec.ok && Tr < 0.03125) decided = dec.decide(F0, F1, F2, Tr, S, (t > 0 ? t : 0) + 1, rgba);
+    }
+    if (PARTIAL) {
+        float res[kPartial];
+        finish_partial<T>(vol, r, step, s_lut, F0, F1, F2, Tr, S, res);
+        if (lane == 0) {
+            float *o = partial_out + (size_t)e.pixel_id * kPartial;
+            for (int k = 0; k < kPartial; k++) o[k] = res[k];
+        }
+        return false;
     }
     if (!decided) {
         // back-most tap: its colour enters unweighted by its alpha (VolumeRendering.comp:189-191)
@@ -1266,8 +1360,11 @@ __device__ __forceinline__ bool continue_ray(const VolumeView &vol, const FrameP
 
 // The rays k_march_fast ran out of lane budget on, one wave per ray; rays still undecided at the back
 // join the replay queue.
+#ifndef VR_LONG_MIN_WAVES
+#define VR_LONG_MIN_WAVES 1
+#endif
 template <typename T, bool STATS>
-__global__ __launch_bounds__(256) void k_march_long(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
+__global__ __launch_bounds__(256, VR_LONG_MIN_WAVES) void k_march_long(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
                                                    float4 border, const LutInfo *__restrict__ info,
                                                    uint32_t *__restrict__ out, Counters *ctr, uint32_t *touched,
                                                    uint32_t *__restrict__ queue, const LongRay *__restrict__ long_queue,

@@ -25,23 +25,6 @@
 
 namespace vr {
 
-constexpr int kPartial = 5;             // floats per pixel of a partial result
-// A box stops marching a ray once the transmittance of its own taps is below this: what it leaves
-// out changes the ray's colour by at most 2 * kTrCut * (largest colour), which k_decide_partials
-// adds to its error interval.
-constexpr double kTrCut = 0x1p-20;
-
-// Cell of a tap in the coordinates of this context's brick box; false when another box owns the tap.
-__device__ __forceinline__ bool tap_cell_local(const Tap &p, const VolumeView &v, Cell &c)
-{
-    c = tap_cell(p, v);
-    c.sx -= v.ox;
-    c.sy -= v.oy;
-    c.sz -= v.oz;
-    return (unsigned)c.sx < (unsigned)(v.nbx * kBrick) && (unsigned)c.sy < (unsigned)(v.nby * kBrick) &&
-           (unsigned)c.sz < (unsigned)(v.nbz * kBrick);
-}
-
 // Whether the texel coordinate of an axis grows with the tap index, i.e. towards the eye
 // (sign of RayModel::b).  Every rank evaluates these expressions on the same inputs, so all agree.
 struct Towards {
@@ -82,190 +65,43 @@ __device__ __forceinline__ float ray_step(const Ray &r, int samples)
 }
 
 // ---- partial march ------------------------------------------------------------------------------
-// Writes a ray's partial result; adds the back-most tap first when the box owns it.
-template <typename T>
-__device__ __forceinline__ void finish_partial(const VolumeView &vol, const Ray &r, float step, const float4 *s_lut,
-                                               double F0, double F1, double F2, double Tr, float S, float *o)
-{
-    if (!(Tr < kTrCut)) {
-        // back-most tap, if it is this box's: its colour enters unweighted (VolumeRendering.comp:189-191)
-        const Tap p = tap_position(r, vol, step, 0);
-        Cell c;
-        if (tap_cell_local(p, vol, c)) {
-            const float4 tf = sample_tf(s_lut, sample_volume<T>(c, brick_of(c, vol), vol));
-            F0 = __builtin_fma(Tr, (double)tf.x, F0);
-            F1 = __builtin_fma(Tr, (double)tf.y, F1);
-            F2 = __builtin_fma(Tr, (double)tf.z, F2);
-            Tr = 0.0;
-        }
-    }
-    o[0] = (float)F0;
-    o[1] = (float)F1;
-    o[2] = (float)F2;
-    o[3] = (float)Tr;
-    o[4] = S;
-}
-
-// One lane per ray, front to back over the taps this context owns, stepping over empty space like
-// k_march_fast.  out: kPartial floats per pixel of the rectangle.  A lane that has fetched `budget`
-// taps with more to go hands its ray to k_partial_long.
+// One lane per ray, front to back over the taps this context owns: the lane march of the whole-volume
+// path (march_lanes) with the ownership test, without the decision.  out: kPartial floats per pixel.
+// A lane that has spent `budget` memory round trips with more to go hands its ray to k_partial_long.
 template <typename T>
 __global__ __launch_bounds__(256) void k_march_partial(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
-                                                      float4 border, float *__restrict__ out, Counters *ctr,
-                                                      LongRay *__restrict__ long_queue, int budget)
+                                                      float4 border, const LutInfo *__restrict__ info,
+                                                      float *__restrict__ out, Counters *ctr,
+                                                      LongRay *__restrict__ long_queue, int budget,
+                                                      const uint2 *__restrict__ tiles, int tiles_x)
 {
     __shared__ float4 s_lut[kLutLds];
     stage_lut(s_lut, lut, border);
+    const Decider dec(info);
     int px, py;
     uint32_t pixel_id;
     const bool in_rect = lane_pixel(fp, px, py, pixel_id);
-    const Ray r = make_ray(fp, in_rect ? px : fp.x0, in_rect ? py : fp.y0);
-    const int last = fp.samples + 1;
-    const float step = ray_step(r, fp.samples);
-    const RayModel rm = ray_model(r, vol, step, -1.0f);
-
-    double F0 = 0.0, F1 = 0.0, F2 = 0.0, Tr = 1.0;
-    float S = 0.0f;
-    int t = last < rm.t_first ? last : rm.t_first;
-    bool marching = in_rect && r.hit;
-    uint32_t solid = 0xffffffffu;
-    unsigned long long solid_mask = 0;
-    bool in_air = true;
-    for (int round = 0; round < budget; round++) {
-        bool have = false;
-        Cell c;
-        uint32_t brick = 0;
-        while (marching && !have) {
-            if (t < rm.t_stop) { marching = false; break; }
-            if (in_air) {
-                const int n = empty_span(vol, rm, t);
-                if (n > 0) {
-                    t -= n;
-                    continue;
-                }
-            }
-            const Tap p = tap_position(r, vol, step, t);
-            if (!tap_cell_local(p, vol, c)) {   // another box's tap (only near the faces of this one)
-                t -= 1;
-                in_air = true;
-                continue;
-            }
-            brick = brick_of(c, vol);
-            if (brick != solid) {
-                const int level = empty_level(vol, c.sx >> 3, c.sy >> 3, c.sz >> 3);
-                if (level >= 0) {
-                    const int n = empty_span_at(vol, rm, t, level, c.sx >> 3, c.sy >> 3, c.sz >> 3);
-                    t -= n > 1 ? n : 1;
-                    in_air = true;
-                    continue;
-                }
-                solid = brick;
-                solid_mask = vol.micro[brick];
-            }
-            in_air = false;
-            if (micro_empty(solid_mask, c)) {
-                const int n = block_span(rm, t, c);
-                t -= n > 1 ? n : 1;
-            } else {
-                have = true;
-            }
-        }
-        if (__ballot(have) == 0ull) break;
-        if (have) {
-            const float4 tf = sample_tf(s_lut, sample_volume<T>(c, brick, vol));
-            if (tf.w != 0.0f) {
-                const double a = (double)tf.w;
-                const double w = Tr * a;
-                F0 = __builtin_fma(w, (double)tf.x, F0);
-                F1 = __builtin_fma(w, (double)tf.y, F1);
-                F2 = __builtin_fma(w, (double)tf.z, F2);
-                S += (float)Tr;
-                Tr = Tr * (1.0 - a);
-                if (Tr < kTrCut) marching = false;
-            }
-            t -= 1;
-        }
-    }
-    if (!in_rect) return;
-    float *o = out + (size_t)pixel_id * kPartial;
-    if (!r.hit) {
-        o[0] = o[1] = o[2] = o[3] = o[4] = 0.0f;
-        return;
-    }
-    if (marching) {
-        // out of budget with taps left: a wave continues this ray (k_partial_long)
-        LongRay e;
-        e.pixel_id = pixel_id; e.t = t; e.S = S; e.pad_ = 0.0f;
-        e.F0 = F0; e.F1 = F1; e.F2 = F2; e.Tr = Tr;
-        long_queue[atomicAdd(&ctr->long_count, 1u)] = e;
-        return;
-    }
-    finish_partial<T>(vol, r, step, s_lut, F0, F1, F2, Tr, S, o);
+    march_lanes<T, false, true>(vol, fp, s_lut, dec, nullptr, ctr, nullptr, nullptr, long_queue, &ctr->long_count, budget, in_rect,
+                                px, py, pixel_id, out, tiles, tiles_x);
 }
 
-// Continuation of the rays k_march_partial ran out of budget on, one wave per ray, 64 consecutive
-// taps per round, folded front to back in tap order (the accumulation of k_march_partial).
+// Continuation of the rays k_march_partial ran out of budget on, one wave per ray (continue_ray).
 template <typename T>
 __global__ __launch_bounds__(256) void k_partial_long(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
-                                                     float4 border, float *__restrict__ out, const Counters *ctr,
-                                                     const LongRay *__restrict__ long_queue)
+                                                     float4 border, const LutInfo *__restrict__ info,
+                                                     float *__restrict__ out, Counters *ctr,
+                                                     const LongRay *__restrict__ long_queue,
+                                                     const uint2 *__restrict__ tiles, int tiles_x)
 {
     __shared__ float4 s_lut[kLutLds];
     stage_lut(s_lut, lut, border);
-    const int lane = threadIdx.x & 63;
+    const Decider dec(info);
     const uint32_t waves = gridDim.x * 4u;
     const uint32_t entries = ctr->long_count;
     for (uint32_t entry = blockIdx.x * 4u + (threadIdx.x >> 6); entry < entries; entry += waves) {
         const LongRay e = long_queue[entry];
-        int px, py;
-        pixel_of_index(fp, e.pixel_id, px, py);
-        const Ray r = make_ray(fp, px, py);          // identical in every lane
-        const float step = ray_step(r, fp.samples);
-        const RayModel rm = ray_model(r, vol, step, -1.0f);
-        double F0 = e.F0, F1 = e.F1, F2 = e.F2, Tr = e.Tr;
-        float S = e.S;
-        int t = e.t;
-        if (t > rm.t_first) t = rm.t_first;
-        while (t >= rm.t_stop && !(Tr < kTrCut)) {
-            const int n = empty_span(vol, rm, t);   // wave-uniform
-            if (n > 0) {
-                t -= n;
-                continue;
-            }
-            const int tt = t - lane;
-            bool fetch = tt >= rm.t_stop;
-            Cell c;
-            uint32_t brick = 0;
-            if (fetch) {
-                const Tap p = tap_position(r, vol, step, tt);
-                fetch = tap_cell_local(p, vol, c);
-                if (fetch) {
-                    brick = brick_of(c, vol);
-                    if (brick_empty(brick, vol) || micro_empty(vol.micro[brick], c)) fetch = false;
-                }
-            }
-            float4 tf = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (fetch) tf = sample_tf(s_lut, sample_volume<T>(c, brick, vol));
-            unsigned long long todo = __ballot(fetch && tf.w != 0.0f);
-            while (todo && !(Tr < kTrCut)) {
-                const int src = __builtin_ctzll(todo);   // lowest lane = front-most tap of the chunk
-                todo &= todo - 1;
-                const double a = (double)__shfl(tf.w, src);
-                const double w = Tr * a;
-                F0 = __builtin_fma(w, (double)__shfl(tf.x, src), F0);
-                F1 = __builtin_fma(w, (double)__shfl(tf.y, src), F1);
-                F2 = __builtin_fma(w, (double)__shfl(tf.z, src), F2);
-                S += (float)Tr;
-                Tr = Tr * (1.0 - a);
-            }
-            t -= 64;
-        }
-        float res[kPartial];
-        finish_partial<T>(vol, r, step, s_lut, F0, F1, F2, Tr, S, res);
-        if (lane == 0) {
-            float *o = out + (size_t)e.pixel_id * kPartial;
-            for (int k = 0; k < kPartial; k++) o[k] = res[k];
-        }
+        uint32_t rgba;
+        continue_ray<T, false, true>(vol, fp, s_lut, dec, ctr, nullptr, e, rgba, tiles, tiles_x, out);
     }
 }
 

@@ -38,8 +38,10 @@ class SortFirstFrame:
         self.device, self.group = torch.device(device), group
         self.rows = band_rows(height, rank, world)
         self.padded_rows = max(band_rows(height, r, world) for r in range(world))
-        # equal-sized buffers on every rank: gather needs them
-        self.local = torch.zeros((self.padded_rows, width, 4), dtype=torch.uint8, device=self.device)
+        # equal-sized buffers on every rank: gather needs them.  Two of them, used in turn, so that a
+        # frame can be rendered while the previous one is still being gathered.
+        self.locals = [torch.zeros((self.padded_rows, width, 4), dtype=torch.uint8, device=self.device) for _ in range(2)]
+        self.turn = 0
         self.recv = None
         self.frame = None
         if rank == 0:
@@ -48,16 +50,24 @@ class SortFirstFrame:
                 self.perm = torch.from_numpy(band_permutation(height, world, self.padded_rows)).to(self.device)
             self.frame = torch.zeros((height, width, 4), dtype=torch.uint8, device=self.device)
 
+    @property
+    def local(self):
+        """The band buffer of the frame being rendered (the one the next exchange() sends)."""
+        return self.locals[self.turn]
+
     def local_view(self):
         return self.local[: self.rows]
 
     def exchange(self):
-        """Gathers every rank's bands on rank 0 and assembles the frame there (returns it on rank 0)."""
+        """Gathers every rank's bands on rank 0 and assembles the frame there (returns it on rank 0).
+        Afterwards `local` is the other band buffer."""
+        local = self.local
+        self.turn ^= 1
         if self.world == 1:
             # a single part's band buffer already is the frame, row for row
-            self.frame.copy_(self.local[: self.height])
+            self.frame.copy_(local[: self.height])
             return self.frame
-        dist.gather(self.local, gather_list=list(self.recv.unbind(0)) if self.rank == 0 else None, dst=0, group=self.group)
+        dist.gather(local, gather_list=list(self.recv.unbind(0)) if self.rank == 0 else None, dst=0, group=self.group)
         if self.rank == 0:
             flat = self.recv.view(self.world * self.padded_rows, self.width, 4)
             torch.index_select(flat, 0, self.perm, out=self.frame)
