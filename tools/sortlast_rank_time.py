@@ -57,8 +57,24 @@ def main():
                     if k >= 2:
                         ms.append(e0.elapsed_time(e1))
             ms = np.asarray(ms)
+            # the re-march of undecided pixels: one call per stage, here for 0.15 % of the pixels picked at random
+            rng = np.random.default_rng(3)
+            todo = torch.from_numpy(rng.choice(pixels, size=max(1, int(pixels * 0.0015)), replace=False).astype(np.int32)).to("cuda")
+            cin = torch.zeros((todo.numel(), 4), dtype=torch.float32, device="cuda")
+            cout = torch.zeros_like(cin)
+            torch.cuda.synchronize()
+            chain = []
+            with torch.cuda.stream(stream):
+                for stage in range(world):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    c.chain_stage(w, h, todo.data_ptr(), todo.numel(), cin.data_ptr(), cout.data_ptr(), stage, grid, box)
+                    e1.record()
+                    e1.synchronize()
+                    chain.append(e0.elapsed_time(e1))
             out["boxes"].append({"box": box, "bricks": [lo, hi], "partial_ms_mean": float(ms.mean()),
-                                 "partial_ms_max": float(ms.max()), "partial_ms_min": float(ms.min())})
+                                 "partial_ms_max": float(ms.max()), "partial_ms_min": float(ms.min()),
+                                 "chain_stage_ms": [round(x, 3) for x in chain], "chain_pixels": int(todo.numel())})
             print(json.dumps(out["boxes"][-1]), flush=True)
     # merge + decide of one rank's span (world images of pixels/world partials), synthetic partials
     with vr.VolumeRenderer(0) as c:

@@ -1120,10 +1120,10 @@ int vr_chain_stage(vr_ctx *ctx, int width, int height, const uint32_t *d_pixels,
     const vr::BoxGrid g{grid[0], grid[1], grid[2]};
     const unsigned blocks = (unsigned)std::min<uint64_t>((count + 3) / 4, 2048);
     if (ctx->dtype == VR_DTYPE_U8)
-        hipLaunchKernelGGL((vr::k_chain_exact<uint8_t>), dim3(blocks), dim3(256), 0, ctx->stream, vol, fp, lut, border, d_pixels, (uint32_t)count,
+        hipLaunchKernelGGL((vr::k_chain_exact<uint8_t>), dim3(blocks), dim3(256), 0, ctx->stream, vol, fp, lut, border, ctx->lut_info, d_pixels, (uint32_t)count,
                            reinterpret_cast<const float4 *>(d_colour_in), reinterpret_cast<float4 *>(d_colour_out), stage, g, box[0], box[1], box[2]);
     else
-        hipLaunchKernelGGL((vr::k_chain_exact<uint16_t>), dim3(blocks), dim3(256), 0, ctx->stream, vol, fp, lut, border, d_pixels, (uint32_t)count,
+        hipLaunchKernelGGL((vr::k_chain_exact<uint16_t>), dim3(blocks), dim3(256), 0, ctx->stream, vol, fp, lut, border, ctx->lut_info, d_pixels, (uint32_t)count,
                            reinterpret_cast<const float4 *>(d_colour_in), reinterpret_cast<float4 *>(d_colour_out), stage, g, box[0], box[1], box[2]);
     VR_HIP(ctx, hipGetLastError());
     return VR_OK;

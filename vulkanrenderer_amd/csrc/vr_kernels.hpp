@@ -203,6 +203,17 @@ __device__ __forceinline__ uint32_t brick_of(const Cell &c, const VolumeView &v)
     return (uint32_t)(((c.sz >> 3) * v.nby + (c.sy >> 3)) * v.nbx + (c.sx >> 3));
 }
 
+// Cell of a tap in the coordinates of this context's brick box; false when another box owns the tap.
+__device__ __forceinline__ bool tap_cell_local(const Tap &p, const VolumeView &v, Cell &c)
+{
+    c = tap_cell(p, v);
+    c.sx -= v.ox;
+    c.sy -= v.oy;
+    c.sz -= v.oz;
+    return (unsigned)c.sx < (unsigned)(v.nbx * kBrick) && (unsigned)c.sy < (unsigned)(v.nby * kBrick) &&
+           (unsigned)c.sz < (unsigned)(v.nbz * kBrick);
+}
+
 // texture(volumeTexture, tc).x with linear filtering and clamp-to-border (border .r = 0):
 // VolumeRendering.comp:187-188, sampler main.cpp:365-382.  In two halves so that a lane can have
 // the loads of several taps in flight before it filters the first: the eight corners of a tap as

@@ -669,11 +669,15 @@ struct Decider {
 // the back after all.  Needs alphas in [0,1] and finite colours (Decider::ok).
 constexpr double kReplayDark = 0x1p-40;
 
-template <typename T, bool STATS>
+//
+// With PARTIAL (sort-last) the fold covers the taps of this context's box only and starts from the
+// colour `carried` in from the boxes behind; the result goes to `result` instead of the frame.  If the
+// box's own taps make the ray dark the two bounding folds meet and what was carried in does not matter.
+template <typename T, bool STATS, bool PARTIAL = false>
 __device__ __forceinline__ void replay_ray(const VolumeView &vol, const FrameParams &fp, const float4 *s_lut,
                                            const Decider &dec, uint32_t *__restrict__ out, Counters *ctr,
                                            uint32_t *touched, uint32_t out_index, const uint2 *__restrict__ tiles,
-                                           int tiles_x)
+                                           int tiles_x, const float *carried = nullptr, float *result = nullptr)
 {
     const int lane = threadIdx.x & 63;
     int px, py;
@@ -699,9 +703,13 @@ __device__ __forceinline__ void replay_ray(const VolumeView &vol, const FramePar
             const int tt = t - lane;
             double keep = 1.0;
             if (tt >= fm.t_stop) {
-                const Cell c = tap_cell(tap_position(r, vol, step, tt), vol);
+                Cell c;
+                bool mine = true;
+                if (PARTIAL) mine = tap_cell_local(tap_position(r, vol, step, tt), vol, c);
+                else c = tap_cell(tap_position(r, vol, step, tt), vol);
+                if (!mine) c.sx = c.sy = c.sz = 0;
                 const uint32_t brick = brick_of(c, vol);
-                if (!(brick_empty(brick, vol) || micro_empty(vol.micro[brick], c))) {
+                if (mine && !(brick_empty(brick, vol) || micro_empty(vol.micro[brick], c))) {
                     keep = 1.0 - (double)sample_tf(s_lut, sample_volume<T>(c, brick, vol)).w;
                     if (STATS) {
                         evaluated++;
@@ -730,6 +738,10 @@ __device__ __forceinline__ void replay_ray(const VolumeView &vol, const FramePar
                 lo[c] = dec.cmin[c] - slack;
                 hi[c] = dec.cmax[c] + slack;
             }
+        } else if (PARTIAL) {
+            lo[0] = hi[0] = carried[0];
+            lo[1] = hi[1] = carried[1];
+            lo[2] = hi[2] = carried[2];
         } else {
             lo[0] = lo[1] = lo[2] = hi[0] = hi[1] = hi[2] = 0.0f;
         }
@@ -750,9 +762,12 @@ __device__ __forceinline__ void replay_ray(const VolumeView &vol, const FramePar
             uint32_t brick = 0;
             if (fetch) {
                 const Tap p = tap_position(r, vol, step, t);
-                c = tap_cell(p, vol);
-                brick = brick_of(c, vol);
-                if (t > 0 && (brick_empty(brick, vol) || micro_empty(vol.micro[brick], c))) fetch = false;
+                if (PARTIAL) fetch = tap_cell_local(p, vol, c);
+                else c = tap_cell(p, vol);
+                if (fetch) {
+                    brick = brick_of(c, vol);
+                    if (t > 0 && (brick_empty(brick, vol) || micro_empty(vol.micro[brick], c))) fetch = false;
+                }
             }
             float4 tf = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (fetch) {
@@ -787,6 +802,10 @@ __device__ __forceinline__ void replay_ray(const VolumeView &vol, const FramePar
                          __float_as_uint(lo[2]) == __float_as_uint(hi[2]);
         if (start == 0 || met) break;
         start = 0;   // the two folds did not meet: fold the whole ray
+    }
+    if (PARTIAL) {
+        for (int c = 0; c < 3; c++) result[c] = r.hit ? lo[c] : carried[c];
+        return;
     }
     if (!r.hit) { lo[0] = lo[1] = lo[2] = 0.0f; }
     if (lane == 0) out[out_index] = pack_rgba8(lo[0], lo[1], lo[2]);
@@ -838,17 +857,6 @@ constexpr int kPartial = 5;             // floats per pixel of a partial result
 // out changes the ray's colour by at most 2 * kTrCut * (largest colour), which k_decide_partials
 // adds to its error interval.
 constexpr double kTrCut = 0x1p-20;
-
-// Cell of a tap in the coordinates of this context's brick box; false when another box owns the tap.
-__device__ __forceinline__ bool tap_cell_local(const Tap &p, const VolumeView &v, Cell &c)
-{
-    c = tap_cell(p, v);
-    c.sx -= v.ox;
-    c.sy -= v.oy;
-    c.sz -= v.oz;
-    return (unsigned)c.sx < (unsigned)(v.nbx * kBrick) && (unsigned)c.sy < (unsigned)(v.nby * kBrick) &&
-           (unsigned)c.sz < (unsigned)(v.nbz * kBrick);
-}
 
 // Writes a ray's partial result; adds the back-most tap first when the box owns it.
 template <typename T>

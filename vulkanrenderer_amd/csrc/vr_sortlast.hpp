@@ -233,17 +233,20 @@ __global__ __launch_bounds__(256) void k_decide_partials(FrameParams fp, const L
 // next stage.  After the last stage it is the shader's colour.  One wave per ray, as k_replay_exact.
 template <typename T>
 __global__ __launch_bounds__(256) void k_chain_exact(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
-                                                    float4 border, const uint32_t *__restrict__ list, uint32_t entries,
+                                                    float4 border, const LutInfo *__restrict__ info,
+                                                    const uint32_t *__restrict__ list, uint32_t entries,
                                                     const float4 *__restrict__ c_in, float4 *__restrict__ c_out, int stage,
                                                     BoxGrid grid, int ci, int cj, int ck)
 {
     __shared__ float4 s_lut[kLutLds];
     stage_lut(s_lut, lut, border);
+    const Decider dec(info);
     const int lane = threadIdx.x & 63;
     const uint32_t waves = gridDim.x * 4u;
     for (uint32_t entry = blockIdx.x * 4u + (threadIdx.x >> 6); entry < entries; entry += waves) {
         Ray r;
-        const bool valid = ray_of_pixel(fp, list[entry], r);   // identical in every lane
+        const uint32_t pixel = list[entry];
+        const bool valid = ray_of_pixel(fp, pixel, r);   // identical in every lane
         const float step = valid ? ray_step(r, fp.samples) : 0.0f;
         const Towards u = march_direction(r, step, vol.fx, vol.fy, vol.fz);
         if (!valid || visit_rank(u, grid, ci, cj, ck) != stage) {
@@ -251,54 +254,10 @@ __global__ __launch_bounds__(256) void k_chain_exact(VolumeView vol, FrameParams
             continue;
         }
         const float4 carried = c_in[entry];
-        float cr = carried.x, cg = carried.y, cb = carried.z;
-        if (r.hit) {
-            const int last = fp.samples + 1;
-            const RayModel rm = ray_model(r, vol, step, 1.0f);
-            int base = 0;
-            while (base <= last) {
-                if (base > 0) {
-                    if (base < rm.t_stop) base = rm.t_stop;
-                    if (base > rm.t_first || base > last) break;
-                    const int n = empty_span(vol, rm, base);
-                    if (n > 0) {
-                        base += n;
-                        continue;
-                    }
-                }
-                const int t = base + lane;
-                bool fetch = t <= last;
-                Cell c;
-                uint32_t brick = 0;
-                if (fetch) {
-                    const Tap p = tap_position(r, vol, step, t);
-                    fetch = tap_cell_local(p, vol, c);
-                    if (fetch) {
-                        brick = brick_of(c, vol);
-                        if (t > 0 && (brick_empty(brick, vol) || micro_empty(vol.micro[brick], c))) fetch = false;
-                    }
-                }
-                float4 tf = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (fetch) tf = sample_tf(s_lut, sample_volume<T>(c, brick, vol));
-                const bool identity = tf.w == 0.0f && isfinite(tf.x) && isfinite(tf.y) && isfinite(tf.z);
-                unsigned long long todo = __ballot(fetch && (t == 0 || !identity));
-                while (todo) {
-                    const int src = __builtin_ctzll(todo);
-                    todo &= todo - 1;
-                    const float a = __shfl(tf.w, src), x = __shfl(tf.x, src), y = __shfl(tf.y, src), z = __shfl(tf.z, src);
-                    if (base + src == 0) {
-                        cr = x; cg = y; cb = z;
-                    } else {
-                        const float ia = 1.0f - a;
-                        cr = a * x + ia * cr;
-                        cg = a * y + ia * cg;
-                        cb = a * z + ia * cb;
-                    }
-                }
-                base += 64;
-            }
-        }
-        if (lane == 0) c_out[entry] = make_float4(cr, cg, cb, 0.0f);
+        const float in[3] = {carried.x, carried.y, carried.z};
+        float res[3];
+        replay_ray<T, false, true>(vol, fp, s_lut, dec, nullptr, nullptr, nullptr, pixel, nullptr, 0, in, res);
+        if (lane == 0) c_out[entry] = make_float4(res[0], res[1], res[2], 0.0f);
     }
 }
 
