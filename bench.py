@@ -86,10 +86,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    # Rehearsal switches (not used by a normal run): several ranks on one GPU, exchanging over gloo
+    # through host memory, to exercise the multi-rank control flow where only one GPU is at hand.
+    backend = os.environ.get("VR_BENCH_BACKEND", "nccl")
+    if os.environ.get("VR_BENCH_ONE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     n, w, h = args.volume, args.width, args.height
     samples = samples_for(n)
@@ -109,7 +117,7 @@ def main():
     ctx.set_mode(mode)
     t_setup = time.perf_counter() - t_setup
 
-    sf = SortFirstFrame(w, h, rank, world, device)
+    sf = SortFirstFrame(w, h, rank, world, device, host_staging=backend != "nccl")
     lib_stream = torch.cuda.ExternalStream(ctx.stream, device=device)
     target = sf.frame if world == 1 else sf.local
     gathered = [None, None]      # per band buffer: event after the gather that last read it
@@ -146,7 +154,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms = ctx.march_kernel_times(min(args.steps, 1024))

@@ -456,3 +456,21 @@ def test_orbit_example_writes_the_checkers_frames(oracle, tmp_path):
         vp, m = oracle.camera(float(hdeg * rad), float(np.float32(25.0) * rad), w, h)
         want = oracle.render(vol, lut, vp[4:8], m, w, h, samples)
         assert np.array_equal(got, want[..., :3]), f
+
+
+def test_bench_with_two_ranks_on_one_gpu(tmp_path):
+    """bench.py's multi-rank control flow (band split, two band buffers in turn, gather, assembly, max over
+    ranks), rehearsed with two ranks on this GPU exchanging over gloo; a small workload."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VR_BENCH_BACKEND="gloo", VR_BENCH_ONE_DEVICE="1")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(29500 + os.getpid() % 2000), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6",
+                          "--warmup", "2", "--volume", "128", "--width", "320", "--height", "200", "--stats-frames", "2"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 6 and line["value"] > 0 and line["unit"] == "Gsamples/s"
+    assert "roofline" in line and line["roofline"]["frac"] > 0

@@ -33,9 +33,11 @@ class SortFirstFrame:
     in the CPU tests it is the checker.
     """
 
-    def __init__(self, width, height, rank, world, device, group=None):
+    def __init__(self, width, height, rank, world, device, group=None, host_staging=False):
         self.width, self.height, self.rank, self.world = width, height, rank, world
         self.device, self.group = torch.device(device), group
+        # gloo cannot gather GPU tensors: a rehearsal of several ranks on one GPU stages through the host
+        self.staging = host_staging
         self.rows = band_rows(height, rank, world)
         self.padded_rows = max(band_rows(height, r, world) for r in range(world))
         # equal-sized buffers on every rank: gather needs them.  Two of them, used in turn, so that a
@@ -67,7 +69,15 @@ class SortFirstFrame:
             # a single part's band buffer already is the frame, row for row
             self.frame.copy_(local[: self.height])
             return self.frame
-        dist.gather(local, gather_list=list(self.recv.unbind(0)) if self.rank == 0 else None, dst=0, group=self.group)
+        if self.staging:
+            host = local.cpu()
+            parts = [torch.empty_like(host) for _ in range(self.world)] if self.rank == 0 else None
+            dist.gather(host, gather_list=parts, dst=0, group=self.group)
+            if self.rank == 0:
+                for r in range(self.world):
+                    self.recv[r].copy_(parts[r])
+        else:
+            dist.gather(local, gather_list=list(self.recv.unbind(0)) if self.rank == 0 else None, dst=0, group=self.group)
         if self.rank == 0:
             flat = self.recv.view(self.world * self.padded_rows, self.width, 4)
             torch.index_select(flat, 0, self.perm, out=self.frame)
