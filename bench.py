@@ -75,6 +75,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if os.environ.get("VR_BENCH_WATCHDOG"):
+        # rehearsals only: a rank stuck for this many seconds prints its Python stacks and exits
+        import faulthandler
+        log = open(os.environ["VR_BENCH_WATCHDOG_FILE"] + "." + os.environ.get("RANK", "0"), "w") if os.environ.get("VR_BENCH_WATCHDOG_FILE") else sys.stderr
+        faulthandler.dump_traceback_later(float(os.environ["VR_BENCH_WATCHDOG"]), exit=True, file=log)
     import torch
     import torch.distributed as dist
 
@@ -89,6 +94,9 @@ def main():
     # Rehearsal switches (not used by a normal run): several ranks on one GPU, exchanging over gloo
     # through host memory, to exercise the multi-rank control flow where only one GPU is at hand.
     backend = os.environ.get("VR_BENCH_BACKEND", "nccl")
+    if not os.environ.get("VR_BENCH_ONE_DEVICE"):
+        # every rank has a GPU of its own: the kernels that finish a frame may run at high stream priority
+        os.environ.setdefault("VR_TAIL_PRIORITY", "1")
     if os.environ.get("VR_BENCH_ONE_DEVICE"):
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -120,19 +128,24 @@ def main():
     sf = SortFirstFrame(w, h, rank, world, device, host_staging=backend != "nccl")
     lib_stream = torch.cuda.ExternalStream(ctx.stream, device=device)
     target = sf.frame if world == 1 else sf.local
+    # Two frames in flight: the few rays a frame's main march hands over are finished beside the next
+    # frame's march, so consecutive frames go to two output buffers in turn.  Every frame is complete
+    # when the timed region ends (fence() below waits for both streams).
+    ctx.set_pipeline(2)
+    targets = [target, torch.zeros_like(target)] if world == 1 else None
     gathered = [None, None]      # per band buffer: event after the gather that last read it
 
     def frame(step):
         ctx.set_camera(*orbit_camera(step))
         if world == 1:
-            ctx.render_bands(w, h, 0, 1, ptr=target.data_ptr())
+            ctx.render_bands(w, h, 0, 1, ptr=targets[step & 1].data_ptr())
             return
         # two band buffers in turn: this frame is rendered while the previous one is still in the gather
         turn = sf.turn
         if gathered[turn] is not None:
             lib_stream.wait_event(gathered[turn])
         ctx.render_bands(w, h, rank, world, ptr=sf.local.data_ptr())
-        torch.cuda.current_stream().wait_stream(lib_stream)
+        ctx.wait_frame(torch.cuda.current_stream().cuda_stream)      # the gather reads the finished frame
         sf.exchange()
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
@@ -208,6 +221,7 @@ def main():
                             "transfer function, 360-frame orbit at 1 deg/step, mode %s" % (n, w, h, samples, args.mode),
                 "volume": [n, n, n], "image": [w, h], "samples_per_ray": samples, "mode": args.mode,
                 "parallelism": "sort-first x%d (16-row bands, replicated volume, RCCL gather)" % world if world > 1 else "single GPU",
+                "frames_in_flight": 2,
                 "setup_s": round(t_setup, 2),
             },
             "roofline": {

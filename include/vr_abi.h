@@ -134,6 +134,19 @@ int vr_render(vr_ctx *ctx, int width, int height, uint8_t *out, int out_is_devic
 int vr_render_rect(vr_ctx *ctx, int width, int height, int x0, int y0, int x1, int y1,
                    uint8_t *out, int out_is_device, vr_stats *stats);
 
+/* Two frames in flight (no counterpart in the reference, which waits on a fence every frame,
+ * Source/VulkanApplication.cpp:560-562).  With frames_in_flight == 2, VR_MODE_FAST frames rendered
+ * into device memory without a stats pointer are pipelined: the kernels that finish a frame (the few
+ * rays the main march hands over) run on a second stream beside the main march of the next frame.
+ * Rules for the caller: consecutive such frames must go to different output buffers; a frame is
+ * complete on stream `s` after vr_wait_frame(ctx, s), or on the host after vr_synchronize(); work
+ * enqueued directly on vr_stream() is NOT ordered after the last frame.  Every other entry point
+ * first lets the frames in flight finish.  Default: 1 (a frame is complete on the context's stream
+ * when vr_render returns). */
+int vr_set_pipeline(vr_ctx *ctx, int frames_in_flight);
+/* Makes `stream` (a hipStream_t, NULL = the default stream) wait for the most recent frame. */
+int vr_wait_frame(vr_ctx *ctx, void *stream);
+
 /* Sort-first split for multi-GPU rendering (no counterpart in the reference, which drives one
  * GPU): the frame's rows are cut into bands of 16 rows, dealt round-robin to `parts` renderers;
  * this call renders the bands b with b % parts == part in one launch and writes them densely,

@@ -465,12 +465,61 @@ def test_bench_with_two_ranks_on_one_gpu(tmp_path):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, VR_BENCH_BACKEND="gloo", VR_BENCH_ONE_DEVICE="1")
+    env = dict(os.environ, VR_BENCH_BACKEND="gloo", VR_BENCH_ONE_DEVICE="1", VR_BENCH_WATCHDOG="90")
     res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", str(29500 + os.getpid() % 2000), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6",
                           "--warmup", "2", "--volume", "128", "--width", "320", "--height", "200", "--stats-frames", "2"],
-                         capture_output=True, text=True, timeout=300, env=env, cwd=root)
+                         capture_output=True, text=True, timeout=120, env=env, cwd=root)
     assert res.returncode == 0, res.stderr[-2000:]
     line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["steps"] == 6 and line["value"] > 0 and line["unit"] == "Gsamples/s"
     assert "roofline" in line and line["roofline"]["frac"] > 0
+
+
+def test_two_frames_in_flight_render_the_same_frames(ctx, oracle, torch):
+    """vr_set_pipeline(2): the finishing kernels of a frame overlap the next frame's march; every frame,
+    each in a buffer of its own or in two buffers used in turn, equals the frame rendered alone."""
+    n, w, h, samples = 96, 200, 150, 300
+    vox = oracle.phantom(n, np.uint16)
+    ctx.upload_volume(vox)
+    ctx.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+    ctx.set_sampling(samples)
+    ctx.set_mode(1)
+    cams = [(math.radians(-170.0 + 37.0 * k), math.radians(20.0 - 9.0 * k)) for k in range(7)]
+    alone = []
+    for cam in cams:
+        ctx.set_camera(*cam)
+        alone.append(ctx.render(w, h))
+    ctx.set_pipeline(2)
+    bufs = [torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda") for _ in cams]
+    torch.cuda.synchronize()
+    for cam, b in zip(cams, bufs):
+        ctx.set_camera(*cam)
+        ctx.render_device(w, h, b.data_ptr())
+    ctx.synchronize()
+    for k, b in enumerate(bufs):
+        assert np.array_equal(b.cpu().numpy(), alone[k]), k
+    # two buffers in turn, each frame read back through a stream that waits for it
+    pair = [torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    got = []
+    for k, cam in enumerate(cams):
+        ctx.set_camera(*cam)
+        ctx.render_device(w, h, pair[k & 1].data_ptr())
+        if k >= 1:
+            # frame k - 1 sits in the other buffer; its finishing kernels may still be running
+            pass
+        ctx.wait_frame(torch.cuda.current_stream().cuda_stream)
+        got.append(pair[k & 1].cpu().numpy().copy())      # .cpu() synchronises torch's stream: the buffer is free again
+    for k in range(len(cams)):
+        assert np.array_equal(got[k], alone[k]), k
+    # a transfer-function change between pipelined frames is ordered after the frames in flight
+    ctx.set_camera(*cams[0])
+    ctx.render_device(w, h, pair[0].data_ptr())
+    ctx.update_transfer_function([cf.TF_GRAPHS[0], cf.TF_GRAPHS[1], cf.TF_GRAPHS[2], [(0, 0.0), (200, 0.0), (483, 0.9)]])
+    ctx.render_device(w, h, pair[1].data_ptr())
+    ctx.synchronize()
+    assert np.array_equal(pair[0].cpu().numpy(), alone[0])
+    ctx.set_pipeline(1)
+    assert np.array_equal(ctx.render(w, h), pair[1].cpu().numpy())
+    assert not np.array_equal(pair[1].cpu().numpy(), alone[0])

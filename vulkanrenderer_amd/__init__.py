@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     "vr_control_point_intensity", "vr_set_camera", "vr_set_camera_raw", "vr_get_camera",
     "vr_camera_uniforms",
     "vr_set_sampling", "vr_set_mode", "vr_render", "vr_render_rect", "vr_render_bands",
-    "vr_band_rows", "vr_march_kernel_times", "vr_count_hit_rays",
+    "vr_band_rows", "vr_set_pipeline", "vr_wait_frame", "vr_march_kernel_times", "vr_count_hit_rays",
     "vr_phantom_generate_device", "vr_phantom_generate_box_device",
     "vr_brick_grid", "vr_subvolume_voxels", "vr_upload_subvolume_device", "vr_render_partial",
     "vr_composite_pair", "vr_composite_ordered", "vr_decide_partials", "vr_chain_stage",
@@ -98,6 +98,8 @@ def lib():
     L.vr_render.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.POINTER(Stats)]
     L.vr_render_rect.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.POINTER(Stats)]
     L.vr_render_bands.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.POINTER(Stats)]
+    L.vr_set_pipeline.argtypes = [vp, C.c_int]
+    L.vr_wait_frame.argtypes = [vp, vp]
     L.vr_band_rows.argtypes = [C.c_int, C.c_int, C.c_int]
     L.vr_march_kernel_times.argtypes = [vp, fp, C.c_int, C.POINTER(C.c_int)]
     L.vr_count_hit_rays.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
@@ -313,6 +315,15 @@ class VolumeRenderer:
         if ptr is None:
             return (out, st.as_dict()) if stats else out
         return st.as_dict() if stats else None
+
+    def set_pipeline(self, frames_in_flight):
+        """2: fast frames into device memory overlap their finishing kernels with the next frame's march
+        (alternate the output buffers and use wait_frame / synchronize before reading a frame)."""
+        self._check(lib().vr_set_pipeline(self._h, frames_in_flight))
+
+    def wait_frame(self, stream_handle):
+        """Makes a stream (its hipStream_t as an integer; 0 = default stream) wait for the last frame."""
+        self._check(lib().vr_wait_frame(self._h, stream_handle))
 
     def march_kernel_times(self, frames):
         """Device milliseconds of the march kernel of the last `frames` frames (<= 1024)."""

@@ -83,6 +83,21 @@ struct vr_ctx {
     uint32_t *queue = nullptr;         // pixels the fast march hands to the reference-order march
     size_t queue_cap = 0;
     vr::LongRay *long_queue = nullptr; // rays the lane march hands to the wave march
+    // Two frames in flight (vr_set_pipeline): fast frames alternate between the buffers above and this
+    // second set, and the kernels that finish a frame run on a stream of their own, beside the next
+    // frame's march.
+    int pipeline_depth = 1;
+    hipStream_t tail_stream = nullptr;
+    hipEvent_t main_done[2] = {nullptr, nullptr}, tail_done[2] = {nullptr, nullptr}, frame_done = nullptr;
+    bool tail_busy[2] = {false, false};
+    int last_set = -1;
+    uint64_t pipe_index = 0;
+    vr::Counters *counters_alt = nullptr;
+    uint32_t *queue_alt = nullptr;
+    vr::LongRay *long_alt = nullptr;
+    size_t alt_queue_cap = 0;
+    uint2 *tiles_alt = nullptr;
+    size_t alt_tiles_cap = 0;
 };
 
 namespace {
@@ -106,8 +121,20 @@ int bind(vr_ctx *ctx)
     return VR_OK;
 }
 
+// Orders the context's stream after the frame-finishing kernels still running on the tail stream:
+// whatever is enqueued next may overwrite what they read.
+void drain(vr_ctx *ctx)
+{
+    for (int k = 0; k < 2; k++)
+        if (ctx->tail_busy[k]) {
+            (void)hipStreamWaitEvent(ctx->stream, ctx->tail_done[k], 0);
+            ctx->tail_busy[k] = false;
+        }
+}
+
 void release_volume(vr_ctx *ctx)
 {
+    drain(ctx);
     if (ctx->bricks) (void)hipFree(ctx->bricks);
     if (ctx->cells) (void)hipFree(ctx->cells);
     if (ctx->touched) (void)hipFree(ctx->touched);
@@ -266,6 +293,7 @@ int check_dims(vr_ctx *ctx, int dtype, int nx, int ny, int nz)
 int refresh_occupancy(vr_ctx *ctx)
 {
     if (!ctx->occupancy_dirty) return VR_OK;
+    drain(ctx);   // frames still being finished read the tables rebuilt here
     const float4 border = make_float4(ctx->border[0], ctx->border[1], ctx->border[2], ctx->border[3]);
     hipLaunchKernelGGL(vr::k_lut_derive, dim3(1), dim3(256), 0, ctx->stream, reinterpret_cast<const float4 *>(ctx->lut), border,
                        ctx->lut_info);
@@ -318,8 +346,17 @@ int rows_of_part(int rows, int part, int parts)
     return (mine - 1) * 16 + last_rows;
 }
 
+struct FrameBuffers {
+    vr::Counters *counters;
+    uint32_t *queue;
+    vr::LongRay *long_queue;
+    uint2 *tiles;
+    hipStream_t tail;        // stream of the kernels that finish the frame
+    hipEvent_t main_done;    // recorded after the lane march when the tail runs on another stream, else null
+};
+
 template <typename T>
-void launch_frame(vr_ctx *ctx, const vr::FrameParams &fp, uint32_t *d_out, bool stats)
+void launch_frame(vr_ctx *ctx, const vr::FrameParams &fp, uint32_t *d_out, bool stats, const FrameBuffers &fb)
 {
     // one wave per 8x8 tile; a band of 16 rows is two tile rows
     const int tiles = ((fp.x1 - fp.x0 + 7) / 8) * 2 * bands_of_part(fp.y1 - fp.y0, fp.part, fp.parts);
@@ -334,15 +371,15 @@ void launch_frame(vr_ctx *ctx, const vr::FrameParams &fp, uint32_t *d_out, bool 
     (void)hipEventRecord(ctx->ring_a[slot], s);
     if (ctx->mode == VR_MODE_REFERENCE_ORDER) {
         if (stats)
-            hipLaunchKernelGGL((vr::k_march_exact<T, false, true>), grid, block, 0, s, vol, fp, lut, border, d_out, ctx->counters, ctx->touched);
+            hipLaunchKernelGGL((vr::k_march_exact<T, false, true>), grid, block, 0, s, vol, fp, lut, border, d_out, fb.counters, ctx->touched);
         else
-            hipLaunchKernelGGL((vr::k_march_exact<T, false, false>), grid, block, 0, s, vol, fp, lut, border, d_out, ctx->counters, ctx->touched);
+            hipLaunchKernelGGL((vr::k_march_exact<T, false, false>), grid, block, 0, s, vol, fp, lut, border, d_out, fb.counters, ctx->touched);
         (void)hipEventRecord(ctx->ring_b[slot], s);
     } else if (ctx->mode == VR_MODE_REFERENCE_SKIP) {
         if (stats)
-            hipLaunchKernelGGL((vr::k_march_exact<T, true, true>), grid, block, 0, s, vol, fp, lut, border, d_out, ctx->counters, ctx->touched);
+            hipLaunchKernelGGL((vr::k_march_exact<T, true, true>), grid, block, 0, s, vol, fp, lut, border, d_out, fb.counters, ctx->touched);
         else
-            hipLaunchKernelGGL((vr::k_march_exact<T, true, false>), grid, block, 0, s, vol, fp, lut, border, d_out, ctx->counters, ctx->touched);
+            hipLaunchKernelGGL((vr::k_march_exact<T, true, false>), grid, block, 0, s, vol, fp, lut, border, d_out, fb.counters, ctx->touched);
         (void)hipEventRecord(ctx->ring_b[slot], s);
     } else {
         // depth range of the occupied bricks per tile of the frame, then the front-to-back march, then the
@@ -350,24 +387,30 @@ void launch_frame(vr_ctx *ctx, const vr::FrameParams &fp, uint32_t *d_out, bool 
         const int tile_px = 1 << vr::kRangeShift;
         const int tiles_x = (fp.width + tile_px - 1) / tile_px, tiles_y = (fp.height + tile_px - 1) / tile_px;
         const uint2 *tiles = nullptr;
-        if (ctx->tile_clip && ctx->tiles && ctx->occ_count > 0) {
-            (void)hipMemsetAsync(ctx->tiles, 0, (size_t)tiles_x * tiles_y * sizeof(uint2), s);
+        if (ctx->tile_clip && fb.tiles && ctx->occ_count > 0) {
+            (void)hipMemsetAsync(fb.tiles, 0, (size_t)tiles_x * tiles_y * sizeof(uint2), s);
             hipLaunchKernelGGL(vr::k_splat_bricks, dim3((ctx->occ_count + 255) / 256), dim3(256), 0, s, vol, fp, ctx->occ_list, ctx->occ_count,
-                               ctx->tiles, tiles_x, tiles_y, ctx->counters);
-            tiles = ctx->tiles;
+                               fb.tiles, tiles_x, tiles_y, fb.counters);
+            tiles = fb.tiles;
             (void)hipEventRecord(ctx->ring_a[slot], s);   // the ring times the march kernel alone
         }
         const dim3 replay_grid(2048);  // 8192 waves, one ray each per pass
+        if (stats)
+            hipLaunchKernelGGL((vr::k_march_fast<T, true>), grid, block, 0, s, vol, fp, lut, border, ctx->lut_info, d_out, fb.counters, ctx->touched, fb.queue, fb.long_queue, ctx->lane_budget, tiles, tiles_x);
+        else
+            hipLaunchKernelGGL((vr::k_march_fast<T, false>), grid, block, 0, s, vol, fp, lut, border, ctx->lut_info, d_out, fb.counters, ctx->touched, fb.queue, fb.long_queue, ctx->lane_budget, tiles, tiles_x);
+        (void)hipEventRecord(ctx->ring_b[slot], s);
+        hipStream_t ts = fb.tail;
+        if (fb.main_done) {
+            (void)hipEventRecord(fb.main_done, s);
+            (void)hipStreamWaitEvent(ts, fb.main_done, 0);
+        }
         if (stats) {
-            hipLaunchKernelGGL((vr::k_march_fast<T, true>), grid, block, 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue, ctx->long_queue, ctx->lane_budget, tiles, tiles_x);
-            (void)hipEventRecord(ctx->ring_b[slot], s);
-            hipLaunchKernelGGL((vr::k_march_long<T, true>), replay_grid, dim3(256), 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue, ctx->long_queue, tiles, tiles_x);
-            hipLaunchKernelGGL((vr::k_replay_exact<T, true>), replay_grid, dim3(256), 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue, tiles, tiles_x);
+            hipLaunchKernelGGL((vr::k_march_long<T, true>), replay_grid, dim3(256), 0, ts, vol, fp, lut, border, ctx->lut_info, d_out, fb.counters, ctx->touched, fb.queue, fb.long_queue, tiles, tiles_x);
+            hipLaunchKernelGGL((vr::k_replay_exact<T, true>), replay_grid, dim3(256), 0, ts, vol, fp, lut, border, ctx->lut_info, d_out, fb.counters, ctx->touched, fb.queue, tiles, tiles_x);
         } else {
-            hipLaunchKernelGGL((vr::k_march_fast<T, false>), grid, block, 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue, ctx->long_queue, ctx->lane_budget, tiles, tiles_x);
-            (void)hipEventRecord(ctx->ring_b[slot], s);
-            hipLaunchKernelGGL((vr::k_march_long<T, false>), replay_grid, dim3(256), 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue, ctx->long_queue, tiles, tiles_x);
-            hipLaunchKernelGGL((vr::k_replay_exact<T, false>), replay_grid, dim3(256), 0, s, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->touched, ctx->queue, tiles, tiles_x);
+            hipLaunchKernelGGL((vr::k_march_long<T, false>), replay_grid, dim3(256), 0, ts, vol, fp, lut, border, ctx->lut_info, d_out, fb.counters, ctx->touched, fb.queue, fb.long_queue, tiles, tiles_x);
+            hipLaunchKernelGGL((vr::k_replay_exact<T, false>), replay_grid, dim3(256), 0, ts, vol, fp, lut, border, ctx->lut_info, d_out, fb.counters, ctx->touched, fb.queue, tiles, tiles_x);
         }
     }
 }
@@ -416,8 +459,20 @@ int vr_destroy(vr_ctx *ctx)
 {
     if (!ctx) return VR_OK;
     (void)hipSetDevice(ctx->device);
+    if (ctx->tail_stream) (void)hipStreamSynchronize(ctx->tail_stream);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    ctx->tail_busy[0] = ctx->tail_busy[1] = false;
     release_volume(ctx);
+    if (ctx->counters_alt) (void)hipFree(ctx->counters_alt);
+    if (ctx->queue_alt) (void)hipFree(ctx->queue_alt);
+    if (ctx->long_alt) (void)hipFree(ctx->long_alt);
+    if (ctx->tiles_alt) (void)hipFree(ctx->tiles_alt);
+    for (int k = 0; k < 2; k++) {
+        if (ctx->main_done[k]) (void)hipEventDestroy(ctx->main_done[k]);
+        if (ctx->tail_done[k]) (void)hipEventDestroy(ctx->tail_done[k]);
+    }
+    if (ctx->frame_done) (void)hipEventDestroy(ctx->frame_done);
+    if (ctx->tail_stream) (void)hipStreamDestroy(ctx->tail_stream);
     if (ctx->lut) (void)hipFree(ctx->lut);
     if (ctx->d_pts) (void)hipFree(ctx->d_pts);
     if (ctx->counters) (void)hipFree(ctx->counters);
@@ -448,7 +503,50 @@ int vr_synchronize(vr_ctx *ctx)
 {
     if (!ctx) return VR_ERR_ARG;
     if (int rc = bind(ctx)) return rc;
+    drain(ctx);
     VR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return VR_OK;
+}
+
+int vr_set_pipeline(vr_ctx *ctx, int frames_in_flight)
+{
+    if (!ctx) return VR_ERR_ARG;
+    if (frames_in_flight != 1 && frames_in_flight != 2) return fail(ctx, VR_ERR_ARG, "frames in flight must be 1 or 2");
+    if (int rc = bind(ctx)) return rc;
+    drain(ctx);
+    if (frames_in_flight == 2 && !ctx->tail_stream) {
+        // the second stream, its events and the second set of counters exist only in contexts that ask for them
+        for (int k = 0; k < 2; k++) {
+            VR_HIP(ctx, hipEventCreateWithFlags(&ctx->main_done[k], hipEventDisableTiming));
+            VR_HIP(ctx, hipEventCreateWithFlags(&ctx->tail_done[k], hipEventDisableTiming));
+        }
+        VR_HIP(ctx, hipMalloc(&ctx->counters_alt, sizeof(vr::Counters)));
+        VR_HIP(ctx, hipMemsetAsync(ctx->counters_alt, 0, sizeof(vr::Counters), ctx->stream));
+        // The finishing kernels are short chains of dependent steps and may be given their few waves first
+        // (VR_TAIL_PRIORITY=1).  Opt-in: with several processes sharing one GPU a high-priority queue was
+        // seen to stall the other processes' queues for good, so it is only meant for a GPU of one's own.
+        const char *prio = std::getenv("VR_TAIL_PRIORITY");
+        if (prio && std::atoi(prio) != 0) {
+            int least = 0, greatest = 0;
+            VR_HIP(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+            VR_HIP(ctx, hipStreamCreateWithPriority(&ctx->tail_stream, hipStreamNonBlocking, greatest));
+        } else {
+            VR_HIP(ctx, hipStreamCreateWithFlags(&ctx->tail_stream, hipStreamNonBlocking));
+        }
+    }
+    ctx->pipeline_depth = frames_in_flight;
+    return VR_OK;
+}
+
+int vr_wait_frame(vr_ctx *ctx, void *stream)
+{
+    if (!ctx) return VR_ERR_ARG;
+    if (int rc = bind(ctx)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (!ctx->frame_done) VR_HIP(ctx, hipEventCreateWithFlags(&ctx->frame_done, hipEventDisableTiming));
+    VR_HIP(ctx, hipEventRecord(ctx->frame_done, ctx->stream));
+    VR_HIP(ctx, hipStreamWaitEvent(s, ctx->frame_done, 0));
+    if (ctx->last_set >= 0 && ctx->tail_busy[ctx->last_set]) VR_HIP(ctx, hipStreamWaitEvent(s, ctx->tail_done[ctx->last_set], 0));
     return VR_OK;
 }
 
@@ -630,6 +728,7 @@ int vr_set_transfer_function(vr_ctx *ctx, const vr_ctrl_pt *const points[4], con
         ctx->d_pts_cap = cap;
     }
     ctx->occupancy_dirty = true;
+    drain(ctx);   // frames still being finished read the table
     if (reset_state) VR_HIP(ctx, hipMemsetAsync(ctx->lut, 0, 1024 * sizeof(float), ctx->stream));
     if (!packed.empty()) {
         // synchronous on purpose: `packed` lives on this stack frame
@@ -778,19 +877,61 @@ static int render_impl(vr_ctx *ctx, int width, int height, int x0, int y0, int x
             ctx->tiles_cap = tile_count;
         }
     }
+    // Two frames in flight: only for fast frames into device memory without counters.  Every other
+    // frame first lets the frames in flight finish and then runs on the one stream.
+    const bool piped = fast && out_is_device && !want_stats && ctx->pipeline_depth == 2;
+    if (!piped || ctx->occupancy_dirty) drain(ctx);
     if (ctx->mode != VR_MODE_REFERENCE_ORDER)
         if (int rc = refresh_occupancy(ctx)) return rc;
+    FrameBuffers fb{ctx->counters, ctx->queue, ctx->long_queue, ctx->tiles, ctx->stream, nullptr};
+    int set = 0;
+    if (piped) {
+        set = (int)(ctx->pipe_index++ & 1u);
+        if (set == 1) {
+            const int tile_px = 1 << vr::kRangeShift;
+            const size_t tile_count = (size_t)((width + tile_px - 1) / tile_px) * (size_t)((height + tile_px - 1) / tile_px);
+            if (pixels > ctx->alt_queue_cap || tile_count > ctx->alt_tiles_cap) {
+                drain(ctx);
+                VR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                if (ctx->queue_alt) (void)hipFree(ctx->queue_alt);
+                if (ctx->long_alt) (void)hipFree(ctx->long_alt);
+                if (ctx->tiles_alt) (void)hipFree(ctx->tiles_alt);
+                ctx->queue_alt = nullptr; ctx->long_alt = nullptr; ctx->tiles_alt = nullptr;
+                ctx->alt_queue_cap = ctx->alt_tiles_cap = 0;
+                VR_HIP(ctx, hipMalloc(&ctx->queue_alt, pixels * sizeof(uint32_t)));
+                VR_HIP(ctx, hipMalloc(&ctx->long_alt, pixels * sizeof(vr::LongRay)));
+                VR_HIP(ctx, hipMalloc(&ctx->tiles_alt, tile_count * sizeof(uint2)));
+                ctx->alt_queue_cap = pixels;
+                ctx->alt_tiles_cap = tile_count;
+            }
+            fb = FrameBuffers{ctx->counters_alt, ctx->queue_alt, ctx->long_alt, ctx->tiles_alt, ctx->stream, nullptr};
+        }
+        // this set's buffers were last used by the frame before the previous one
+        if (ctx->tail_busy[set]) {
+            VR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->tail_done[set], 0));
+            ctx->tail_busy[set] = false;
+        }
+        fb.tail = ctx->tail_stream;
+        fb.main_done = ctx->main_done[set];
+    }
     // the counters also carry the fast march's queue fill, so they are cleared every frame
-    VR_HIP(ctx, hipMemsetAsync(ctx->counters, 0, offsetof(vr::Counters, lut_error), ctx->stream));
+    VR_HIP(ctx, hipMemsetAsync(fb.counters, 0, offsetof(vr::Counters, lut_error), ctx->stream));
     if (want_stats)
         VR_HIP(ctx, hipMemsetAsync(ctx->touched, 0, ((ctx->brick_count + 31) / 32) * sizeof(uint32_t), ctx->stream));
 
     VR_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     if (ctx->dtype == VR_DTYPE_U8)
-        launch_frame<uint8_t>(ctx, fp, d_out, want_stats);
+        launch_frame<uint8_t>(ctx, fp, d_out, want_stats, fb);
     else
-        launch_frame<uint16_t>(ctx, fp, d_out, want_stats);
+        launch_frame<uint16_t>(ctx, fp, d_out, want_stats, fb);
     VR_HIP(ctx, hipGetLastError());
+    if (piped) {
+        VR_HIP(ctx, hipEventRecord(ctx->tail_done[set], ctx->tail_stream));
+        ctx->tail_busy[set] = true;
+        ctx->last_set = set;
+    } else {
+        ctx->last_set = -1;
+    }
     VR_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
 
     if (!out_is_device) {
@@ -891,6 +1032,7 @@ int vr_count_hit_rays(vr_ctx *ctx, int width, int height, int x0, int y0, int x1
     fp.samples = ctx->samples;
     fp.part = 0;
     fp.parts = 1;
+    drain(ctx);
     VR_HIP(ctx, hipMemsetAsync(ctx->counters, 0, offsetof(vr::Counters, lut_error), ctx->stream));
     const int tiles = ((x1 - x0 + 7) / 8) * 2 * ((y1 - y0 + 15) / 16);
     hipLaunchKernelGGL(vr::k_count_hits, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, ctx->stream, fp, &ctx->counters->rays_hit);
@@ -983,6 +1125,7 @@ int vr_render_partial(vr_ctx *ctx, int width, int height, float *out, int out_is
     if (int rc = frame_params(ctx, width, height, fp)) return rc;
     const size_t pixels = (size_t)width * height;
     float *d_out = out;
+    drain(ctx);
     if (!out_is_device) {
         if (pixels > ctx->partial_cap) {
             if (ctx->partial) (void)hipFree(ctx->partial);
