@@ -65,7 +65,7 @@ def cpu_baseline(threads=0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=120)
+    ap.add_argument("--steps", type=int, default=360, help="frames timed; 360 = the whole orbit at 1 degree a step")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--volume", type=int, default=2048, help="phantom edge length in voxels")
     ap.add_argument("--width", type=int, default=3840)
@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--mode", choices=("fast", "reference", "reference_skip"), default="fast")
     ap.add_argument("--stats-frames", type=int, default=12, help="frames measured with counters for the roofline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shading", action="store_true",
+                    help="switch on the shader's commented-out lighting (not the headline workload: the reference renders without it)")
     args = ap.parse_args()
 
     if os.environ.get("VR_BENCH_WATCHDOG"):
@@ -94,8 +96,9 @@ def main():
     # Rehearsal switches (not used by a normal run): several ranks on one GPU, exchanging over gloo
     # through host memory, to exercise the multi-rank control flow where only one GPU is at hand.
     backend = os.environ.get("VR_BENCH_BACKEND", "nccl")
-    if not os.environ.get("VR_BENCH_ONE_DEVICE"):
-        # every rank has a GPU of its own: the kernels that finish a frame may run at high stream priority
+    if world == 1:
+        # the only process on its GPU: the kernels that finish a frame may run at high stream priority
+        # (with several ranks the collective's own kernels share the GPU's queues, so they keep the default)
         os.environ.setdefault("VR_TAIL_PRIORITY", "1")
     if os.environ.get("VR_BENCH_ONE_DEVICE"):
         local_rank = 0
@@ -123,6 +126,8 @@ def main():
     ctx.update_transfer_function(TF_GRAPHS, reset_state=True)
     ctx.set_sampling(samples, (0.0, 0.0, 0.0, 0.0))
     ctx.set_mode(mode)
+    if args.shading:
+        ctx.set_shading(True)
     t_setup = time.perf_counter() - t_setup
 
     sf = SortFirstFrame(w, h, rank, world, device, host_staging=backend != "nccl")
@@ -172,6 +177,24 @@ def main():
         elapsed = float(t.item())
     kernel_ms = ctx.march_kernel_times(min(args.steps, 1024))
 
+    # latency of single frames (untimed pass, one frame at a time on one stream): the spread over the orbit
+    latency = None
+    if world == 1:
+        ctx.set_pipeline(1)
+        marks = []
+        for i in range(args.steps):
+            ctx.set_camera(*orbit_camera(i))
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(lib_stream)
+            ctx.render_bands(w, h, 0, 1, ptr=target.data_ptr())
+            b.record(lib_stream)
+            marks.append((a, b))
+        ctx.synchronize()
+        ms = np.array([a.elapsed_time(b) for a, b in marks])
+        latency = {"mean": float(ms.mean()), "p5": float(np.percentile(ms, 5)), "p50": float(np.percentile(ms, 50)),
+                   "p95": float(np.percentile(ms, 95)), "frames": int(ms.size)}
+        ctx.set_pipeline(2)
+
     # work of the timed frames: what the reference shader would execute
     nominal = 0
     if rank == 0:
@@ -211,6 +234,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "frames_per_s": args.steps / elapsed,
+            "single_frame_ms": latency,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -218,10 +242,11 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "%d^3 uint16 Shepp-Logan phantom, %dx%d, %d samples/ray (half-voxel on the diagonal), 4-point "
-                            "transfer function, 360-frame orbit at 1 deg/step, mode %s" % (n, w, h, samples, args.mode),
+                            "transfer function, 360-frame orbit at 1 deg/step, mode %s%s" % (n, w, h, samples, args.mode, ", gradient lighting on" if args.shading else ""),
                 "volume": [n, n, n], "image": [w, h], "samples_per_ray": samples, "mode": args.mode,
                 "parallelism": "sort-first x%d (16-row bands, replicated volume, RCCL gather)" % world if world > 1 else "single GPU",
                 "frames_in_flight": 2,
+                "shading": bool(args.shading),
                 "setup_s": round(t_setup, 2),
             },
             "roofline": {

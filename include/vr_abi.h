@@ -124,6 +124,17 @@ int vr_camera_uniforms(float horizontal_rad, float vertical_rad, int width, int 
 int vr_set_sampling(vr_ctx *ctx, int samples_per_ray, const float tf_border_rgba[4]);
 int vr_set_mode(vr_ctx *ctx, int mode);
 
+/* Local illumination: the gradient normal (computeNormal, VolumeRendering.comp:109-119) and the
+ * Blinn-Phong term (shading, :123-152) that the shader adds to a tap's colour at :195-198 -- lines its
+ * author has commented out, so the reference itself renders with enabled = 0, the default here.
+ * scene = the push constants `Scene` {ambient, diffuse, specular, shininess} (main.cpp:80-98, pushed
+ * at :808; sliders :1212-1215 keep them in [0,1]^3 x [1,128], enforced here); NULL = the reference's
+ * values {1, 1, 1, 100}.  Light at (0,0,-1), light colour 1, ambient light 0.3 as in the shader.
+ * normalize() of a zero vector, undefined in GLSL, yields the zero vector (a tap in a flat
+ * neighbourhood gets the ambient term only).  Works in every mode; frames stay identical between
+ * the modes.  Contexts holding a sub-volume refuse it (the gradient reads beyond the box's apron). */
+int vr_set_shading(vr_ctx *ctx, int enabled, const float scene[4]);
+
 /* One frame: the dispatch of VolumeRendering.comp (main.cpp:823-828) and its imageStore
  * (VolumeRendering.comp:205).  out: width*height*4 bytes RGBA8, row-major, pixel (0,0) first;
  * a host pointer (out_is_device == 0, copied back and synchronised) or a device pointer

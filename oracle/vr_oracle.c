@@ -456,12 +456,58 @@ static inline ray_t make_ray(const float *loc, const float *m, int px, int py)
     return r;
 }
 
+/* The local illumination the shader carries but has commented out (VolumeRendering.comp:195-198):
+ * computeNormal (:109-119), shading (:123-152), with the push constants `Scene` (main.cpp:80-98,808).
+ * scene = { ambient, diffuse, specular, shininess }.  Returns the one float the shader adds to all
+ * three colour channels (light colour (1,1,1) and ambient light (0.3,0.3,0.3) are grey).
+ * Conventions beyond the shader text:
+ *   - normalize(v) = v * (1 / sqrt((x*x + y*y) + z*z)) as for the ray direction;
+ *   - normalize of the zero vector, undefined in GLSL (a flat neighbourhood has gradient 0 and would
+ *     turn the pixel into NaN), gives the zero vector: such a tap gets the ambient term only;
+ *   - dot(a, b) = (a.x*b.x + a.y*b.y) + a.z*b.z; pow is powf. */
+static inline void normalize3(float v[3])
+{
+    const float d = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
+    if (!(d > 0.0f)) { v[0] = v[1] = v[2] = 0.0f; return; }
+    const float inv = 1.0f / sqrtf(d);
+    v[0] *= inv; v[1] *= inv; v[2] *= inv;
+}
+
+static inline float shade_tap(const sampler_state *s, const float loc[4], float x, float y, float z,
+                              float step, const float scene[4])
+{
+    /* computeNormal: central differences one ray step to either side, :111-113 */
+    const float w[3] = { x, y, z }, org[3] = { -0.5f, -0.5f, 0.0f };
+    float n[3];
+    for (int a = 0; a < 3; a++) {
+        float tp[3], tm[3];
+        for (int c = 0; c < 3; c++) {
+            const float off = c == a ? step : 0.0f;
+            tp[c] = fabsf((w[c] + off) - org[c]);
+            tm[c] = fabsf((w[c] - off) - org[c]);
+        }
+        n[a] = (sample_volume(s, tp[0], tp[1], tp[2]) - sample_volume(s, tm[0], tm[1], tm[2])) / (2.0f * step);
+    }
+    normalize3(n);                                                   /* :116 */
+    const float v[3] = { loc[0] - x, loc[1] - y, loc[2] - z };       /* sampleToView, :196 */
+    const float l[3] = { 0.0f - x, 0.0f - y, -1.0f - z };            /* lightLocation (0,0,-1), :169,197 */
+    float h[3] = { l[0] + v[0], l[1] + v[1], l[2] + v[2] };
+    normalize3(h);                                                   /* :137 */
+    const float ambient = scene[0] * 0.3f;                           /* :140 */
+    const float diffuse_light = glsl_max((l[0] * n[0] + l[1] * n[1]) + l[2] * n[2], 0.0f);   /* :143 */
+    const float diffuse = scene[1] * diffuse_light;                  /* :144 */
+    float specular_light = powf(glsl_max((h[0] * n[0] + h[1] * n[1]) + h[2] * n[2], 0.0f), scene[3]);   /* :147 */
+    if (diffuse_light <= 0.0f) specular_light = 0.0f;                /* :148 */
+    const float specular = scene[2] * specular_light;                /* :149 */
+    return (ambient + diffuse) + specular;                           /* :151 */
+}
+
 /* Two clones: one for hosts with FMA3 (fmaf becomes one instruction), one generic (libm fmaf,
  * which is exact as well).  Results are identical; only the speed differs. */
 __attribute__((target_clones("arch=haswell", "default")))
 static void render_rows(const sampler_state *s, const float loc[4], const float m[16],
                         uint32_t width, uint32_t samples, uint32_t row0, uint32_t row1,
-                        uint8_t *out, float *colour, int threads)
+                        uint8_t *out, float *colour, int threads, const float *scene)
 {
 #ifdef _OPENMP
     if (threads <= 0) threads = omp_get_max_threads();
@@ -485,6 +531,10 @@ static void render_rows(const sampler_state *s, const float loc[4], const float 
                     if (t == 0) {                                                 /* :189-191 */
                         C[0] = tf[0]; C[1] = tf[1]; C[2] = tf[2];
                     } else {                                                      /* :200 */
+                        if (scene) {                                              /* :195-198, disabled in the shader */
+                            const float sh = shade_tap(s, loc, x, y, z, step, scene);
+                            tf[0] += sh; tf[1] += sh; tf[2] += sh;
+                        }
                         const float a = tf[3];
                         const float ia = 1.0f - a;
                         C[0] = a * tf[0] + ia * C[0];
@@ -516,7 +566,23 @@ void vro_render_f(const float *volume, uint32_t nx, uint32_t ny, uint32_t nz,
     s.lut = lut;
     memcpy(s.border, tf_border, sizeof s.border);
     if (row1 > height) row1 = height;
-    render_rows(&s, location, to_world, width, samples, row0, row1, out, colour, threads);
+    render_rows(&s, location, to_world, width, samples, row0, row1, out, colour, threads, NULL);
+}
+
+void vro_render_shaded(const float *volume, uint32_t nx, uint32_t ny, uint32_t nz,
+                       const float *lut, const float tf_border[4],
+                       const float location[4], const float to_world[16],
+                       uint32_t width, uint32_t height, uint32_t samples,
+                       uint32_t row0, uint32_t row1, uint8_t *out, float *colour, int threads,
+                       const float scene[4])
+{
+    sampler_state s;
+    s.vol = volume; s.nx = (int)nx; s.ny = (int)ny; s.nz = (int)nz;
+    s.fx = (float)nx; s.fy = (float)ny; s.fz = (float)nz;
+    s.lut = lut;
+    memcpy(s.border, tf_border, sizeof s.border);
+    if (row1 > height) row1 = height;
+    render_rows(&s, location, to_world, width, samples, row0, row1, out, colour, threads, scene);
 }
 
 void vro_render(const float *volume, uint32_t nx, uint32_t ny, uint32_t nz,

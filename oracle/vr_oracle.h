@@ -77,6 +77,17 @@ void vro_render_f(const float *volume, uint32_t nx, uint32_t ny, uint32_t nz,
                   uint32_t width, uint32_t height, uint32_t samples,
                   uint32_t row0, uint32_t row1, uint8_t *out, float *colour, int threads);
 
+/* The same frame with the local illumination the shader has commented out switched on
+ * (VolumeRendering.comp:109-152,195-198; push constants main.cpp:80-98,808):
+ * scene = { ambient, diffuse, specular, shininess }, the reference's values are { 1, 1, 1, 100 }.
+ * normalize() of a zero vector, undefined in GLSL, yields the zero vector here. */
+void vro_render_shaded(const float *volume, uint32_t nx, uint32_t ny, uint32_t nz,
+                       const float *lut, const float tf_border[4],
+                       const float location[4], const float to_world[16],
+                       uint32_t width, uint32_t height, uint32_t samples,
+                       uint32_t row0, uint32_t row1, uint8_t *out, float *colour, int threads,
+                       const float scene[4]);
+
 /* Number of rays of the frame that hit the box (for the nominal sample count). */
 uint64_t vro_count_hits(const float location[4], const float to_world[16],
                         uint32_t width, uint32_t height);

@@ -56,6 +56,8 @@ def lib():
                                    C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                    C.c_void_p, C.c_void_p, C.c_int]
         L.vro_render_f.restype = None
+        L.vro_render_shaded.argtypes = L.vro_render_f.argtypes + [fp]
+        L.vro_render_shaded.restype = None
         L.vro_count_hits.argtypes = [fp, fp, C.c_uint32, C.c_uint32]
         L.vro_count_hits.restype = C.c_uint64
         L.vro_count_hits_rows.argtypes = [fp, fp, C.c_uint32, C.c_uint32, C.c_uint32]
@@ -145,8 +147,9 @@ def histogram(normalized):
 
 
 def render(volume, lut, location, to_world, width, height, samples=200,
-           border=(0.0, 0.0, 0.0, 0.0), rows=None, want_colour=False, threads=0):
-    """volume: float32 [nz, ny, nx] normalised; returns uint8 [height, width, 4] (and colour)."""
+           border=(0.0, 0.0, 0.0, 0.0), rows=None, want_colour=False, threads=0, scene=None):
+    """volume: float32 [nz, ny, nx] normalised; returns uint8 [height, width, 4] (and colour).
+    scene = (ambient, diffuse, specular, shininess) switches on the shader's commented-out lighting."""
     volume = np.ascontiguousarray(volume, np.float32)
     nz, ny, nx = volume.shape
     lut = np.ascontiguousarray(lut, np.float32).ravel()
@@ -156,6 +159,13 @@ def render(volume, lut, location, to_world, width, height, samples=200,
     out = np.zeros((height, width, 4), np.uint8)
     col = np.zeros((height, width, 3), np.float32) if want_colour else None
     r0, r1 = (0, height) if rows is None else rows
+    if scene is not None:
+        sc = np.asarray(scene, np.float32)
+        assert sc.shape == (4,)
+        lib().vro_render_shaded(_fp(volume), nx, ny, nz, _fp(lut), _fp(b), _fp(loc), _fp(m),
+                                width, height, samples, r0, r1, out.ctypes.data,
+                                col.ctypes.data if want_colour else None, threads, _fp(sc))
+        return (out, col) if want_colour else out
     lib().vro_render_f(_fp(volume), nx, ny, nz, _fp(lut), _fp(b), _fp(loc), _fp(m),
                        width, height, samples, r0, r1, out.ctypes.data,
                        col.ctypes.data if want_colour else None, threads)

@@ -55,6 +55,14 @@ CAMERAS = {
 }
 
 
+# push constants `Scene` (ambient, diffuse, specular, shininess): the reference's values (main.cpp:90-98)
+# and a second set inside the sliders' ranges (main.cpp:1212-1215)
+SCENES = {
+    "reference": (1.0, 1.0, 1.0, 100.0),
+    "soft": (0.4, 0.7, 0.25, 12.0),
+}
+
+
 def same_bits(a, b):
     """Bitwise equality of float32 arrays, any NaN equal to any NaN."""
     a = np.ascontiguousarray(a, np.float32).ravel()

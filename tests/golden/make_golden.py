@@ -37,6 +37,12 @@ def main():
         for cname, (h, v) in cf.CAMERAS.items():
             vp, m = o.camera(h, v, 64, 64)
             out["frame_%s_%s" % (tag, cname)] = o.render(vol, lut, vp[4:8], m, 64, 64, 200)
+    # the shader's commented-out lighting switched on, the reference's constants and a second set
+    vol, _ = o.normalize(o.phantom(32, np.uint8))
+    for cname, (h, v) in cf.CAMERAS.items():
+        vp, m = o.camera(h, v, 64, 64)
+        for sname, scene in cf.SCENES.items():
+            out["shaded_u8_32_%s_%s" % (cname, sname)] = o.render(vol, lut, vp[4:8], m, 64, 64, 200, scene=scene)
     np.savez_compressed(os.path.join(HERE, "golden.npz"), **out)
     print("wrote golden.npz with", len(out), "arrays")
 

@@ -458,6 +458,86 @@ def test_orbit_example_writes_the_checkers_frames(oracle, tmp_path):
         assert np.array_equal(got, want[..., :3]), f
 
 
+# ---- the shader's commented-out lighting (VolumeRendering.comp:109-152,195-198) ---------------------
+# The device's powf and the host's may differ in the last bit, so a byte may now and then differ by
+# one from the checker's: the frame bar (<= 1/255, >= 99.9 % exact) applies, not byte equality.  The
+# three modes run the same device code per tap and must agree byte for byte among themselves.
+
+@pytest.mark.parametrize("sname", list(cf.SCENES))
+def test_shaded_golden_frames(ctx, oracle, golden, sname):
+    ctx.upload_volume(oracle.phantom(32, np.uint8))
+    ctx.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+    ctx.set_sampling(200, (0, 0, 0, 0))
+    ctx.set_shading(True, cf.SCENES[sname])
+    for cname, cam in cf.CAMERAS.items():
+        ctx.set_camera(*cam)
+        frames = []
+        for mode in (0, 2, 1):
+            ctx.set_mode(mode)
+            frames.append(ctx.render(64, 64))
+            check_frame(frames[-1], golden["shaded_u8_32_%s_%s" % (cname, sname)], "shaded %s %s mode %d" % (cname, sname, mode),
+                        exact_required=False)
+        assert np.array_equal(frames[0], frames[1]) and np.array_equal(frames[0], frames[2]), (cname, sname)
+    # switching it off again gives the plain frame
+    ctx.set_shading(False)
+    ctx.set_mode(1)
+    check_frame(ctx.render(64, 64), golden["frame_u8_32_" + cname], "shading off again")
+
+
+def test_shaded_frames_larger_volume(ctx, oracle):
+    vox = oracle.phantom(96, np.uint16)
+    w, h, samples = 160, 120, 333
+    ctx.upload_volume(vox)
+    ctx.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+    ctx.set_sampling(samples, (0, 0, 0, 0))
+    ctx.set_shading(True)          # the reference's constants
+    vol, _ = oracle.normalize(vox)
+    lut = np.zeros((256, 4), np.float32)
+    oracle.lut_update(lut, cf.TF_GRAPHS)
+    for cam in (cf.CAMERAS["h30_v20"], cf.CAMERAS["hm135_vm60"]):
+        ctx.set_camera(*cam)
+        vp, m = oracle.camera(cam[0], cam[1], w, h)
+        want = oracle.render(vol, lut, vp[4:8], m, w, h, samples, scene=cf.SCENES["reference"])
+        ctx.set_mode(0)
+        ref = ctx.render(w, h)
+        check_frame(ref, want, "shaded 96^3 reference order", exact_required=False)
+        ctx.set_mode(2)
+        assert np.array_equal(ctx.render(w, h), ref)
+        ctx.set_mode(1)
+        fast, st = ctx.render(w, h, stats=True)
+        assert np.array_equal(fast, ref)
+        assert st["samples_evaluated"] < st["samples_nominal"]
+        # bands and two frames in flight take the same path
+        parts = [ctx.render_bands(w, h, p, 3) for p in range(3)]
+        assert sum(x.shape[0] for x in parts) == h
+
+
+def test_shading_arguments(vr, ctx, oracle):
+    ctx.upload_volume(oracle.phantom(16, np.uint8))
+    for bad in ((-0.1, 0, 0, 10), (0, 1.5, 0, 10), (0, 0, float("nan"), 10), (0, 0, 0, 0.5), (0, 0, 0, 200.0)):
+        with pytest.raises(vr.VrError):
+            ctx.set_shading(True, bad)
+    ctx.set_shading(True, (0.0, 0.0, 0.0, 1.0))
+    # all weights zero: the term adds 0 to every tap
+    ctx.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+    ctx.set_camera(*cf.CAMERAS["h30_v20"])
+    ctx.set_sampling(40)
+    ctx.set_mode(1)
+    zero = ctx.render(40, 40)
+    ctx.set_shading(False)
+    assert np.array_equal(zero, ctx.render(40, 40))
+    # a context holding a box of the volume refuses the lighting, and the other way round
+    from vulkanrenderer_amd import sortlast
+    vox = oracle.phantom(32, np.uint8)
+    ctx.set_shading(True)
+    with pytest.raises(vr.VrError):
+        sortlast.upload_box_of(ctx, vox, (2, 1, 1), (0, 0, 0), "cuda")
+    ctx.set_shading(False)
+    sortlast.upload_box_of(ctx, vox, (2, 1, 1), (0, 0, 0), "cuda")
+    with pytest.raises(vr.VrError):
+        ctx.set_shading(True)
+
+
 def test_bench_with_two_ranks_on_one_gpu(tmp_path):
     """bench.py's multi-rank control flow (band split, two band buffers in turn, gather, assembly, max over
     ranks), rehearsed with two ranks on this GPU exchanging over gloo; a small workload."""

@@ -88,6 +88,39 @@ def test_frames_match_golden(oracle, golden):
             assert np.all(img[..., 3] == 255)
 
 
+def test_shaded_frames_match_golden(oracle, golden):
+    lut = golden["lut_four_points"]
+    vol, _ = oracle.normalize(oracle.phantom(32, np.uint8))
+    for cname, (h, v) in cf.CAMERAS.items():
+        vp, m = oracle.camera(h, v, 64, 64)
+        for sname, scene in cf.SCENES.items():
+            img = oracle.render(vol, lut, vp[4:8], m, 64, 64, 200, scene=scene)
+            assert np.array_equal(img, golden["shaded_u8_32_%s_%s" % (cname, sname)]), (cname, sname)
+            assert not np.array_equal(img, golden["frame_u8_32_" + cname]), (cname, sname)
+
+
+def test_shading_terms(oracle, golden):
+    lut = golden["lut_four_points"]
+    vol, _ = oracle.normalize(oracle.phantom(32, np.uint8))
+    vp, m = oracle.camera(*cf.CAMERAS["h30_v20"], 48, 40)
+    plain = oracle.render(vol, lut, vp[4:8], m, 48, 40, 60)
+    # all three weights zero: the lines add 0 to every colour (VolumeRendering.comp:140-151)
+    assert np.array_equal(oracle.render(vol, lut, vp[4:8], m, 48, 40, 60, scene=(0.0, 0.0, 0.0, 50.0)), plain)
+    # ambient only, everything opaque: the front-most tap's colour + 0.3 * ambient reaches the pixel
+    # (scene.ambient * ambientLight, :134,140); a constant volume has gradient 0 away from its faces
+    const = np.full((8, 8, 8), 0.5, np.float32)
+    flat = np.zeros((256, 4), np.float32)
+    flat[:, 0] = 0.25
+    flat[:, 3] = 1.0
+    vp, m = oracle.camera(0.0, 0.0, 33, 33)
+    img = oracle.render(const, flat, vp[4:8], m, 33, 33, 10, border=(0.25, 0.0, 0.0, 1.0), scene=(1.0, 0.0, 0.0, 1.0))
+    assert tuple(img[16, 16]) == (140, 76, 76, 255)      # round(0.55 * 255), round(0.3 * 255)
+    # a flat neighbourhood (gradient 0) gets the ambient term only, never NaN: diffuse and specular on
+    inner = np.full((16, 16, 16), 0.5, np.float32)
+    img = oracle.render(inner, flat, vp[4:8], m, 33, 33, 0, border=(0.25, 0.0, 0.0, 1.0), scene=(1.0, 1.0, 1.0, 100.0))
+    assert img[16, 16, 1] >= 76
+
+
 def test_render_rows_and_threads_agree(oracle, golden):
     lut = golden["lut_four_points"]
     vol, _ = oracle.normalize(oracle.phantom(32, np.uint8))

@@ -23,7 +23,7 @@ ABI_SYMBOLS = (
     "vr_read_volume_normalized", "vr_histogram", "vr_set_transfer_function", "vr_get_lut",
     "vr_control_point_intensity", "vr_set_camera", "vr_set_camera_raw", "vr_get_camera",
     "vr_camera_uniforms",
-    "vr_set_sampling", "vr_set_mode", "vr_render", "vr_render_rect", "vr_render_bands",
+    "vr_set_sampling", "vr_set_mode", "vr_set_shading", "vr_render", "vr_render_rect", "vr_render_bands",
     "vr_band_rows", "vr_set_pipeline", "vr_wait_frame", "vr_march_kernel_times", "vr_count_hit_rays",
     "vr_phantom_generate_device", "vr_phantom_generate_box_device",
     "vr_brick_grid", "vr_subvolume_voxels", "vr_upload_subvolume_device", "vr_render_partial",
@@ -95,6 +95,7 @@ def lib():
     L.vr_camera_uniforms.argtypes = [C.c_float, C.c_float, C.c_int, C.c_int, fp, fp]
     L.vr_set_sampling.argtypes = [vp, C.c_int, fp]
     L.vr_set_mode.argtypes = [vp, C.c_int]
+    L.vr_set_shading.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
     L.vr_render.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.POINTER(Stats)]
     L.vr_render_rect.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.POINTER(Stats)]
     L.vr_render_bands.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.POINTER(Stats)]
@@ -291,6 +292,14 @@ class VolumeRenderer:
 
     def set_mode(self, mode):
         self._check(lib().vr_set_mode(self._h, mode))
+
+    def set_shading(self, enabled, scene=None):
+        """The shader's commented-out local illumination (VolumeRendering.comp:195-198); scene =
+        (ambient, diffuse, specular, shininess), None = the reference's (1, 1, 1, 100) (main.cpp:90-98)."""
+        sc = None if scene is None else np.ascontiguousarray(scene, np.float32)
+        if sc is not None and sc.shape != (4,):
+            raise ValueError("scene is (ambient, diffuse, specular, shininess)")
+        self._check(lib().vr_set_shading(self._h, 1 if enabled else 0, None if sc is None else _fp(sc)))
 
     # --- frame (renderCommands' dispatch, main.cpp:823-828) -----------------------------------
     def render(self, width, height, stats=False, rect=None):

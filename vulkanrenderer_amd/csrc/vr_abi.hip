@@ -86,6 +86,9 @@ struct vr_ctx {
     // Two frames in flight (vr_set_pipeline): fast frames alternate between the buffers above and this
     // second set, and the kernels that finish a frame run on a stream of their own, beside the next
     // frame's march.
+    // the shader's commented-out local illumination (vr_set_shading)
+    bool shading = false;
+    float scene[4] = {1.0f, 1.0f, 1.0f, 100.0f};   // main.cpp:90-98
     int pipeline_depth = 1;
     hipStream_t tail_stream = nullptr;
     hipEvent_t main_done[2] = {nullptr, nullptr}, tail_done[2] = {nullptr, nullptr}, frame_done = nullptr;
@@ -246,6 +249,7 @@ int ingest_device(vr_ctx *ctx, T *d_raw, int nx, int ny, int nz, float max_value
     if (!(mx > 0.0f)) return fail(ctx, VR_ERR_ARG, "volume is all zero: the reference would divide by zero");
     if (mx > 65535.0f) return fail(ctx, VR_ERR_ARG, "max_value above 65535");
 
+    if (sub && ctx->shading) return fail(ctx, VR_ERR_STATE, "shading is on: a sub-volume's apron does not hold the neighbours the gradient reads");
     release_volume(ctx);
     ctx->nx = nx; ctx->ny = ny; ctx->nz = nz;
     ctx->nbx = hi[0] - lo[0];
@@ -296,7 +300,7 @@ int refresh_occupancy(vr_ctx *ctx)
     drain(ctx);   // frames still being finished read the tables rebuilt here
     const float4 border = make_float4(ctx->border[0], ctx->border[1], ctx->border[2], ctx->border[3]);
     hipLaunchKernelGGL(vr::k_lut_derive, dim3(1), dim3(256), 0, ctx->stream, reinterpret_cast<const float4 *>(ctx->lut), border,
-                       ctx->lut_info);
+                       ctx->shading ? vr::shade_bound(ctx->scene) : 0.0f, ctx->lut_info);
     const unsigned bricks = (unsigned)ctx->brick_count;
     hipLaunchKernelGGL(vr::k_classify_bricks, dim3((bricks + 255) / 256), dim3(256), 0, ctx->stream, ctx->cells, bricks, ctx->inv_hi,
                        ctx->inv_lo, ctx->lut_info, ctx->empty[0]);
@@ -355,8 +359,8 @@ struct FrameBuffers {
     hipEvent_t main_done;    // recorded after the lane march when the tail runs on another stream, else null
 };
 
-template <typename T>
-void launch_frame(vr_ctx *ctx, const vr::FrameParams &fp, uint32_t *d_out, bool stats, const FrameBuffers &fb)
+template <typename T, bool STATS, bool SHADE>
+void launch_frame_as(vr_ctx *ctx, const vr::FrameParams &fp, uint32_t *d_out, const FrameBuffers &fb)
 {
     // one wave per 8x8 tile; a band of 16 rows is two tile rows
     const int tiles = ((fp.x1 - fp.x0 + 7) / 8) * 2 * bands_of_part(fp.y1 - fp.y0, fp.part, fp.parts);
@@ -370,16 +374,10 @@ void launch_frame(vr_ctx *ctx, const vr::FrameParams &fp, uint32_t *d_out, bool 
     ctx->frames++;
     (void)hipEventRecord(ctx->ring_a[slot], s);
     if (ctx->mode == VR_MODE_REFERENCE_ORDER) {
-        if (stats)
-            hipLaunchKernelGGL((vr::k_march_exact<T, false, true>), grid, block, 0, s, vol, fp, lut, border, d_out, fb.counters, ctx->touched);
-        else
-            hipLaunchKernelGGL((vr::k_march_exact<T, false, false>), grid, block, 0, s, vol, fp, lut, border, d_out, fb.counters, ctx->touched);
+        hipLaunchKernelGGL((vr::k_march_exact<T, false, STATS, SHADE>), grid, block, 0, s, vol, fp, lut, border, d_out, fb.counters, ctx->touched);
         (void)hipEventRecord(ctx->ring_b[slot], s);
     } else if (ctx->mode == VR_MODE_REFERENCE_SKIP) {
-        if (stats)
-            hipLaunchKernelGGL((vr::k_march_exact<T, true, true>), grid, block, 0, s, vol, fp, lut, border, d_out, fb.counters, ctx->touched);
-        else
-            hipLaunchKernelGGL((vr::k_march_exact<T, true, false>), grid, block, 0, s, vol, fp, lut, border, d_out, fb.counters, ctx->touched);
+        hipLaunchKernelGGL((vr::k_march_exact<T, true, STATS, SHADE>), grid, block, 0, s, vol, fp, lut, border, d_out, fb.counters, ctx->touched);
         (void)hipEventRecord(ctx->ring_b[slot], s);
     } else {
         // depth range of the occupied bricks per tile of the frame, then the front-to-back march, then the
@@ -395,23 +393,27 @@ void launch_frame(vr_ctx *ctx, const vr::FrameParams &fp, uint32_t *d_out, bool 
             (void)hipEventRecord(ctx->ring_a[slot], s);   // the ring times the march kernel alone
         }
         const dim3 replay_grid(2048);  // 8192 waves, one ray each per pass
-        if (stats)
-            hipLaunchKernelGGL((vr::k_march_fast<T, true>), grid, block, 0, s, vol, fp, lut, border, ctx->lut_info, d_out, fb.counters, ctx->touched, fb.queue, fb.long_queue, ctx->lane_budget, tiles, tiles_x);
-        else
-            hipLaunchKernelGGL((vr::k_march_fast<T, false>), grid, block, 0, s, vol, fp, lut, border, ctx->lut_info, d_out, fb.counters, ctx->touched, fb.queue, fb.long_queue, ctx->lane_budget, tiles, tiles_x);
+        hipLaunchKernelGGL((vr::k_march_fast<T, STATS, SHADE>), grid, block, 0, s, vol, fp, lut, border, ctx->lut_info, d_out, fb.counters, ctx->touched, fb.queue, fb.long_queue, ctx->lane_budget, tiles, tiles_x);
         (void)hipEventRecord(ctx->ring_b[slot], s);
         hipStream_t ts = fb.tail;
         if (fb.main_done) {
             (void)hipEventRecord(fb.main_done, s);
             (void)hipStreamWaitEvent(ts, fb.main_done, 0);
         }
-        if (stats) {
-            hipLaunchKernelGGL((vr::k_march_long<T, true>), replay_grid, dim3(256), 0, ts, vol, fp, lut, border, ctx->lut_info, d_out, fb.counters, ctx->touched, fb.queue, fb.long_queue, tiles, tiles_x);
-            hipLaunchKernelGGL((vr::k_replay_exact<T, true>), replay_grid, dim3(256), 0, ts, vol, fp, lut, border, ctx->lut_info, d_out, fb.counters, ctx->touched, fb.queue, tiles, tiles_x);
-        } else {
-            hipLaunchKernelGGL((vr::k_march_long<T, false>), replay_grid, dim3(256), 0, ts, vol, fp, lut, border, ctx->lut_info, d_out, fb.counters, ctx->touched, fb.queue, fb.long_queue, tiles, tiles_x);
-            hipLaunchKernelGGL((vr::k_replay_exact<T, false>), replay_grid, dim3(256), 0, ts, vol, fp, lut, border, ctx->lut_info, d_out, fb.counters, ctx->touched, fb.queue, tiles, tiles_x);
-        }
+        hipLaunchKernelGGL((vr::k_march_long<T, STATS, SHADE>), replay_grid, dim3(256), 0, ts, vol, fp, lut, border, ctx->lut_info, d_out, fb.counters, ctx->touched, fb.queue, fb.long_queue, tiles, tiles_x);
+        hipLaunchKernelGGL((vr::k_replay_exact<T, STATS, SHADE>), replay_grid, dim3(256), 0, ts, vol, fp, lut, border, ctx->lut_info, d_out, fb.counters, ctx->touched, fb.queue, tiles, tiles_x);
+    }
+}
+
+template <typename T>
+void launch_frame(vr_ctx *ctx, const vr::FrameParams &fp, uint32_t *d_out, bool stats, const FrameBuffers &fb)
+{
+    if (ctx->shading) {
+        if (stats) launch_frame_as<T, true, true>(ctx, fp, d_out, fb);
+        else launch_frame_as<T, false, true>(ctx, fp, d_out, fb);
+    } else {
+        if (stats) launch_frame_as<T, true, false>(ctx, fp, d_out, fb);
+        else launch_frame_as<T, false, false>(ctx, fp, d_out, fb);
     }
 }
 
@@ -809,6 +811,29 @@ int vr_set_sampling(vr_ctx *ctx, int samples_per_ray, const float tf_border_rgba
     return VR_OK;
 }
 
+int vr_set_shading(vr_ctx *ctx, int enabled, const float scene[4])
+{
+    if (!ctx) return VR_ERR_ARG;
+    float next[4] = {1.0f, 1.0f, 1.0f, 100.0f};   // main.cpp:90-98
+    if (scene) {
+        std::memcpy(next, scene, sizeof next);
+        // the window's sliders keep the first three in [0,1] and the exponent in [1,128] (main.cpp:1212-1215)
+        for (int k = 0; k < 3; k++)
+            if (!(next[k] >= 0.0f && next[k] <= 1.0f)) return fail(ctx, VR_ERR_ARG, "ambient, diffuse and specular must lie in [0,1]");
+        if (!(next[3] >= 1.0f && next[3] <= 128.0f)) return fail(ctx, VR_ERR_ARG, "shininess must lie in [1,128]");
+    }
+    if (enabled && ctx->sub) return fail(ctx, VR_ERR_STATE, "the context holds a sub-volume: its apron does not hold the neighbours the gradient reads");
+    const bool on = enabled != 0;
+    if (on != ctx->shading || std::memcmp(next, ctx->scene, sizeof next) != 0) {
+        if (int rc = bind(ctx)) return rc;
+        drain(ctx);
+        ctx->shading = on;
+        std::memcpy(ctx->scene, next, sizeof next);
+        ctx->occupancy_dirty = true;   // the colour range the early decisions rely on includes the illumination
+    }
+    return VR_OK;
+}
+
 int vr_set_mode(vr_ctx *ctx, int mode)
 {
     if (!ctx) return VR_ERR_ARG;
@@ -837,6 +862,7 @@ static int render_impl(vr_ctx *ctx, int width, int height, int x0, int y0, int x
     fp.samples = ctx->samples;
     fp.part = part;
     fp.parts = parts;
+    std::memcpy(fp.scene, ctx->scene, sizeof fp.scene);
 
     const size_t pixels = (size_t)(x1 - x0) * (size_t)rows_of_part(y1 - y0, part, parts);
     if (pixels == 0) {
@@ -1032,6 +1058,7 @@ int vr_count_hit_rays(vr_ctx *ctx, int width, int height, int x0, int y0, int x1
     fp.samples = ctx->samples;
     fp.part = 0;
     fp.parts = 1;
+    std::memcpy(fp.scene, ctx->scene, sizeof fp.scene);
     drain(ctx);
     VR_HIP(ctx, hipMemsetAsync(ctx->counters, 0, offsetof(vr::Counters, lut_error), ctx->stream));
     const int tiles = ((x1 - x0 + 7) / 8) * 2 * ((y1 - y0 + 15) / 16);
@@ -1113,6 +1140,7 @@ static int frame_params(vr_ctx *ctx, int width, int height, vr::FrameParams &fp)
     fp.samples = ctx->samples;
     fp.part = 0;
     fp.parts = 1;
+    std::memcpy(fp.scene, ctx->scene, sizeof fp.scene);
     return VR_OK;
 }
 

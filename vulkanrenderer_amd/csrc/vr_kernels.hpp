@@ -61,6 +61,7 @@ struct FrameParams {
     // Sort-first split: the rectangle's rows are cut into bands of 16 rows and this launch
     // renders the bands b with b % parts == part, written densely one after the other.
     int part, parts;
+    float scene[4];      // push constants `Scene` (main.cpp:80-98): ambient, diffuse, specular, shininess
 };
 
 struct Counters {
@@ -167,17 +168,30 @@ struct Tap {
     float x, y, z;     // u*size - 0.5 per axis
 };
 
-__device__ __forceinline__ Tap tap_position(const Ray &r, const VolumeView &v, float step, int t)
+// sampleLocation of tap t (VolumeRendering.comp:185-186)
+__device__ __forceinline__ void tap_world(const Ray &r, float step, int t, float w[3])
 {
     const float len = r.tmax - (float)t * step;
-    const float wx = r.o[0] + len * r.d[0];
-    const float wy = r.o[1] + len * r.d[1];
-    const float wz = r.o[2] + len * r.d[2];
+    w[0] = r.o[0] + len * r.d[0];
+    w[1] = r.o[1] + len * r.d[1];
+    w[2] = r.o[2] + len * r.d[2];
+}
+
+// abs(location - samplerOrigin) (VolumeRendering.comp:168,187) in unnormalised texel space
+__device__ __forceinline__ Tap tap_of_world(float wx, float wy, float wz, const VolumeView &v)
+{
     Tap p;
     p.x = fabsf(wx - -0.5f) * v.fx - 0.5f;
     p.y = fabsf(wy - -0.5f) * v.fy - 0.5f;
     p.z = fabsf(wz - 0.0f) * v.fz - 0.5f;
     return p;
+}
+
+__device__ __forceinline__ Tap tap_position(const Ray &r, const VolumeView &v, float step, int t)
+{
+    float w[3];
+    tap_world(r, step, t, w);
+    return tap_of_world(w[0], w[1], w[2], v);
 }
 
 struct Cell {
@@ -265,6 +279,73 @@ __device__ __forceinline__ float4 sample_tf(const float4 *s_lut, float intensity
     const int i = safe_index(xf, 256) + 2;
     const float4 a = s_lut[i], b = s_lut[i + 1];
     return make_float4(lerp_fma(w, a.x, b.x), lerp_fma(w, a.y, b.y), lerp_fma(w, a.z, b.z), lerp_fma(w, a.w, b.w));
+}
+
+// ---- local illumination -----------------------------------------------------------------------------
+// The shader carries a gradient + Blinn-Phong term that its author has commented out at the call site
+// (VolumeRendering.comp:195-198; computeNormal :109-119, shading :123-152; push constants `Scene`
+// main.cpp:80-98,808).  shade_tap returns what those lines would add to all three channels of a tap's
+// colour (light colour and ambient light are grey).  normalize() of a zero vector, undefined in GLSL
+// (a flat neighbourhood has gradient 0 and the pixel would turn NaN), gives the zero vector here: such
+// a tap receives the ambient term only.  The value is finite for any input, so a tap whose alpha is
+// exactly 0 still blends as the identity and the marches may leave it out as before.
+__device__ __forceinline__ void normalize3(float v[3])
+{
+    const float d = (v[0] * v[0] + v[1] * v[1]) + v[2] * v[2];
+    if (!(d > 0.0f)) {
+        v[0] = v[1] = v[2] = 0.0f;
+        return;
+    }
+    const float inv = 1.0f / sqrtf(d);
+    v[0] *= inv;
+    v[1] *= inv;
+    v[2] *= inv;
+}
+
+// Largest value shade_tap can return for these constants (|light - sample| <= 1.2248 inside the box).
+__host__ __device__ inline float shade_bound(const float scene[4])
+{
+    return 0.3f * scene[0] + 1.25f * scene[1] + 1.01f * scene[2];
+}
+
+template <typename T, bool STATS>
+__device__ __forceinline__ float shade_tap(const VolumeView &vol, const FrameParams &fp, const Ray &r, float step, int t,
+                                           uint32_t *touched, unsigned long long &evaluated)
+{
+    float w[3];
+    tap_world(r, step, t, w);
+    // central differences one ray step to either side of the tap (:111-113): all six loads first
+    Cell cells[6];
+    uint32_t bricks[6];
+    TapWords raw[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const float off = (k & 1) ? -step : step;
+        const float x = (k >> 1) == 0 ? w[0] + off : w[0], y = (k >> 1) == 1 ? w[1] + off : w[1],
+                    z = (k >> 1) == 2 ? w[2] + off : w[2];
+        cells[k] = tap_cell(tap_of_world(x, y, z, vol), vol);
+        bricks[k] = brick_of(cells[k], vol);
+        raw[k] = fetch_volume<T>(cells[k], bricks[k], vol);
+        if (STATS) atomicOr(&touched[bricks[k] >> 5], 1u << (bricks[k] & 31));
+    }
+    if (STATS) evaluated += 6;
+    float n[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+        n[a] = (filter_volume<T>(raw[2 * a], cells[2 * a], vol) - filter_volume<T>(raw[2 * a + 1], cells[2 * a + 1], vol)) /
+               (2.0f * step);
+    normalize3(n);
+    const float v[3] = {fp.loc[0] - w[0], fp.loc[1] - w[1], fp.loc[2] - w[2]};
+    const float l[3] = {0.0f - w[0], 0.0f - w[1], -1.0f - w[2]};     // lightLocation (0, 0, -1), :169
+    float h[3] = {l[0] + v[0], l[1] + v[1], l[2] + v[2]};
+    normalize3(h);
+    const float ambient = fp.scene[0] * 0.3f;
+    const float diffuse_light = glsl_max((l[0] * n[0] + l[1] * n[1]) + l[2] * n[2], 0.0f);
+    const float diffuse = fp.scene[1] * diffuse_light;
+    float specular_light = powf(glsl_max((h[0] * n[0] + h[1] * n[1]) + h[2] * n[2], 0.0f), fp.scene[3]);
+    if (diffuse_light <= 0.0f) specular_light = 0.0f;
+    const float specular = fp.scene[2] * specular_light;
+    return (ambient + diffuse) + specular;
 }
 
 __device__ __forceinline__ uint32_t to_unorm8(float x)

@@ -34,7 +34,8 @@ struct LutInfo {
 constexpr float kUlpHalf = 5.9604644775390625e-08f;  // 2^-24
 
 // One block.  Derives LutInfo from the table and the border colour.
-__global__ __launch_bounds__(256) void k_lut_derive(const float4 *__restrict__ lut, float4 border, LutInfo *info)
+// shade_hi: largest value the local illumination adds to a tap's colour (0 when it is off).
+__global__ __launch_bounds__(256) void k_lut_derive(const float4 *__restrict__ lut, float4 border, float shade_hi, LutInfo *info)
 {
     __shared__ uint32_t s_bad[kLutLds];
     __shared__ float s_min[3][256], s_max[3][256];
@@ -77,6 +78,7 @@ __global__ __launch_bounds__(256) void k_lut_derive(const float4 *__restrict__ l
             }
         }
         for (int c = 0; c < 3; c++) {
+            hi[c] += shade_hi;   // taps in front of the back-most one carry colour + illumination
             // a filtered colour stays inside [lo, hi] up to one rounding; widen a little
             const float mag = fmaxf(fabsf(lo[c]), fabsf(hi[c]));
             const float slack = mag * 1e-6f + 1e-30f;
@@ -554,7 +556,7 @@ __device__ __forceinline__ int block_span(const RayModel &m, int t, const Cell &
 // lies in an empty cube of the occupancy pyramid is not fetched: its alpha is exactly 0 and the
 // blend a*c + (1-a)*C leaves C unchanged bit for bit.  The back-most tap (t == 0) is always
 // fetched because the shader assigns its colour instead of blending.
-template <typename T, bool SKIP, bool STATS>
+template <typename T, bool SKIP, bool STATS, bool SHADE>
 __global__ __launch_bounds__(256) void k_march_exact(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
                                                     float4 border, uint32_t *__restrict__ out, Counters *ctr,
                                                     uint32_t *touched)
@@ -591,10 +593,14 @@ __global__ __launch_bounds__(256) void k_march_exact(VolumeView vol, FrameParams
                 continue;
             }
             const float inten = sample_volume<T>(c, brick, vol);
-            const float4 tf = sample_tf(s_lut, inten);
+            float4 tf = sample_tf(s_lut, inten);
             if (t == 0) {
                 cr = tf.x; cg = tf.y; cb = tf.z;
             } else {
+                if (SHADE && !(SKIP && tf.w == 0.0f && isfinite(tf.x) && isfinite(tf.y) && isfinite(tf.z))) {
+                    const float sh = shade_tap<T, STATS>(vol, fp, r, step, t, touched, evaluated);
+                    tf.x += sh; tf.y += sh; tf.z += sh;
+                }
                 const float a = tf.w, ia = 1.0f - tf.w;
                 cr = a * tf.x + ia * cr;
                 cg = a * tf.y + ia * cg;
@@ -673,7 +679,7 @@ constexpr double kReplayDark = 0x1p-40;
 // With PARTIAL (sort-last) the fold covers the taps of this context's box only and starts from the
 // colour `carried` in from the boxes behind; the result goes to `result` instead of the frame.  If the
 // box's own taps make the ray dark the two bounding folds meet and what was carried in does not matter.
-template <typename T, bool STATS, bool PARTIAL = false>
+template <typename T, bool STATS, bool PARTIAL = false, bool SHADE = false>
 __device__ __forceinline__ void replay_ray(const VolumeView &vol, const FrameParams &fp, const float4 *s_lut,
                                            const Decider &dec, uint32_t *__restrict__ out, Counters *ctr,
                                            uint32_t *touched, uint32_t out_index, const uint2 *__restrict__ tiles,
@@ -778,6 +784,10 @@ __device__ __forceinline__ void replay_ray(const VolumeView &vol, const FramePar
                 }
             }
             const bool identity = tf.w == 0.0f && isfinite(tf.x) && isfinite(tf.y) && isfinite(tf.z);
+            if (SHADE && fetch && t > 0 && !identity) {
+                const float sh = shade_tap<T, STATS>(vol, fp, r, step, t, touched, evaluated);
+                tf.x += sh; tf.y += sh; tf.z += sh;
+            }
             unsigned long long todo = __ballot(fetch && (t == 0 || !identity));
             while (todo) {
                 const int src = __builtin_ctzll(todo);
@@ -901,7 +911,7 @@ __device__ __forceinline__ void finish_partial(const VolumeView &vol, const Ray 
 // empty space (cheap, divergent), then all lanes that found a tap fetch it together.
 //
 // One lane marches one ray; the 64 rays of a wave are the pixels of an 8x8 tile.
-template <typename T, bool STATS, bool PARTIAL>
+template <typename T, bool STATS, bool PARTIAL, bool SHADE = false>
 __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FrameParams &fp, const float4 *s_lut,
                                             const Decider &dec, uint32_t *__restrict__ out, Counters *ctr,
                                             uint32_t *touched, uint32_t *__restrict__ queue,
@@ -1090,12 +1100,17 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
 #pragma unroll
             for (int k = 0; k < kTapGroup; k++) {
                 if (k >= taps) break;
-                const float4 tf = sample_tf(s_lut, filter_volume<T>(raw[k], cs[k], vol));
+                float4 tf = sample_tf(s_lut, filter_volume<T>(raw[k], cs[k], vol));
                 if (STATS) {
                     evaluated++;
                     atomicOr(&touched[bricks[k] >> 5], 1u << (bricks[k] & 31));
                 }
                 if (tf.w != 0.0f) {
+                    if (SHADE) {
+                        static_assert(!SHADE || !PARTIAL, "a box's apron does not hold the neighbours the gradient reads");
+                        const float sh = shade_tap<T, STATS>(vol, fp, r, step, t - k, touched, evaluated);
+                        tf.x += sh; tf.y += sh; tf.z += sh;
+                    }
                     const double a = (double)tf.w;
                     const double w = Tr * a;
                     F0 = __builtin_fma(w, (double)tf.x, F0);
@@ -1195,7 +1210,7 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
 #endif
 }
 
-template <typename T, bool STATS>
+template <typename T, bool STATS, bool SHADE>
 __global__ __launch_bounds__(256, VR_FAST_MIN_WAVES) void k_march_fast(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
                                                    float4 border, const LutInfo *__restrict__ info,
                                                    uint32_t *__restrict__ out, Counters *ctr, uint32_t *touched,
@@ -1208,7 +1223,7 @@ __global__ __launch_bounds__(256, VR_FAST_MIN_WAVES) void k_march_fast(VolumeVie
     int px, py;
     uint32_t pixel_id;
     const bool in_rect = lane_pixel(fp, px, py, pixel_id);
-    march_lanes<T, STATS, false>(vol, fp, s_lut, dec, out, ctr, touched, queue, long_queue, &ctr->long_count, budget, in_rect, px,
+    march_lanes<T, STATS, false, SHADE>(vol, fp, s_lut, dec, out, ctr, touched, queue, long_queue, &ctr->long_count, budget, in_rect, px,
                                  py, pixel_id, nullptr, tiles, tiles_x);
 }
 
@@ -1244,7 +1259,7 @@ constexpr int kLongTaps = VR_LONG_TAPS;   // consecutive taps per lane and round
 // at a time; the decision test runs once per 64 taps.  Returns whether the bytes are decided.
 // With PARTIAL (sort-last) only the taps of this context's box are taken, nothing is decided, the
 // march stops once the box's own taps have made the ray dark, and the sums go to partial_out.
-template <typename T, bool STATS, bool PARTIAL = false>
+template <typename T, bool STATS, bool PARTIAL = false, bool SHADE = false>
 __device__ __forceinline__ bool continue_ray(const VolumeView &vol, const FrameParams &fp, const float4 *s_lut,
                                              const Decider &dec, Counters *ctr, uint32_t *touched, const LongRay &e,
                                              uint32_t &rgba, const uint2 *__restrict__ tiles, int tiles_x,
@@ -1298,10 +1313,14 @@ __device__ __forceinline__ bool continue_ray(const VolumeView &vol, const FrameP
 #pragma unroll
         for (int k = 0; k < kLongTaps; k++) {
             if (!fetch[k]) continue;
-            const float4 tf = sample_tf(s_lut, filter_volume<T>(raw[k], cs[k], vol));
+            float4 tf = sample_tf(s_lut, filter_volume<T>(raw[k], cs[k], vol));
             if (STATS) {
                 evaluated++;
                 atomicOr(&touched[bricks[k] >> 5], 1u << (bricks[k] & 31));
+            }
+            if (SHADE && tf.w != 0.0f) {
+                const float sh = shade_tap<T, STATS>(vol, fp, r, step, t - (lane * kLongTaps + k), touched, evaluated);
+                tf.x += sh; tf.y += sh; tf.z += sh;
             }
             if (tf.w != 0.0f) blend_under(v, blend_of_tap(true, tf));
         }
@@ -1371,7 +1390,7 @@ __device__ __forceinline__ bool continue_ray(const VolumeView &vol, const FrameP
 #ifndef VR_LONG_MIN_WAVES
 #define VR_LONG_MIN_WAVES 1
 #endif
-template <typename T, bool STATS>
+template <typename T, bool STATS, bool SHADE>
 __global__ __launch_bounds__(256, VR_LONG_MIN_WAVES) void k_march_long(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
                                                    float4 border, const LutInfo *__restrict__ info,
                                                    uint32_t *__restrict__ out, Counters *ctr, uint32_t *touched,
@@ -1387,7 +1406,7 @@ __global__ __launch_bounds__(256, VR_LONG_MIN_WAVES) void k_march_long(VolumeVie
     for (uint32_t entry = blockIdx.x * 4u + (threadIdx.x >> 6); entry < entries; entry += waves) {
         const LongRay e = long_queue[entry];
         uint32_t rgba;
-        const bool decided = continue_ray<T, STATS>(vol, fp, s_lut, dec, ctr, touched, e, rgba, tiles, tiles_x);
+        const bool decided = continue_ray<T, STATS, false, SHADE>(vol, fp, s_lut, dec, ctr, touched, e, rgba, tiles, tiles_x);
         if (lane == 0) {
             if (decided) out[e.pixel_id] = rgba;
             else queue[atomicAdd(&ctr->replay_count, 1u)] = e.pixel_id;
@@ -1396,7 +1415,7 @@ __global__ __launch_bounds__(256, VR_LONG_MIN_WAVES) void k_march_long(VolumeVie
 }
 
 // The rays neither march could decide, re-marched in reference order, one wave per ray.
-template <typename T, bool STATS>
+template <typename T, bool STATS, bool SHADE>
 __global__ __launch_bounds__(256) void k_replay_exact(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
                                                      float4 border, const LutInfo *__restrict__ info,
                                                      uint32_t *__restrict__ out, Counters *ctr, uint32_t *touched,
@@ -1409,7 +1428,7 @@ __global__ __launch_bounds__(256) void k_replay_exact(VolumeView vol, FrameParam
     const uint32_t waves = gridDim.x * 4u;
     const uint32_t entries = ctr->replay_count;
     for (uint32_t entry = blockIdx.x * 4u + (threadIdx.x >> 6); entry < entries; entry += waves)
-        replay_ray<T, STATS>(vol, fp, s_lut, dec, out, ctr, touched, queue[entry], tiles, tiles_x);
+        replay_ray<T, STATS, false, SHADE>(vol, fp, s_lut, dec, out, ctr, touched, queue[entry], tiles, tiles_x);
 }
 
 // Rays of the rectangle that hit the box (the reference marches samples + 2 taps on each).
