@@ -222,7 +222,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("%d_%dx%d_%s" % (n, w, h, args.mode))
+                traffic = json.load(open(tpath)).get("%d_%dx%d_%s%s" % (n, w, h, args.mode, "_shaded" if args.shading else ""))
             except Exception:
                 traffic = None
         line = {
