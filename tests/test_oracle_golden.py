@@ -4,6 +4,7 @@ be built here, so the vectors were produced by the restatement itself (tests/gol
 parity with the reference is unpinned, these tests pin the restatement against change."""
 import math
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -201,3 +202,14 @@ def test_slice_loader_roundtrip(oracle, tmp_path):
 def test_reference_dataset_loads(oracle):
     vol, mx = oracle.load_slices("/root/reference/Applications/VolumeRendering/Dependencies/VolumeData")
     assert vol.shape == (113, 256, 256) and mx == 3272.0   # CThead: 113 slices of 256x256, maximum 3272
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/Applications/VolumeRendering/Dependencies/VolumeData"),
+                    reason="reference datasets are only present in the build container")
+def test_reference_dataset_frame_matches_golden(oracle):
+    # the only real-data case: the dataset stays where the reference is, the committed fixture is the frame
+    sys.path.insert(0, cf.GOLDEN)
+    import make_cthead
+    vol, _ = oracle.load_slices(make_cthead.DATA)
+    want = np.load(os.path.join(cf.GOLDEN, "cthead_frame.npz"))["frame"]
+    assert np.array_equal(make_cthead.render(vol), want)
