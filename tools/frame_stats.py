@@ -1,4 +1,5 @@
-"""Counters of a few benchmark frames (fast mode), for tuning."""
+"""Diagnostic: counters of a few frames of the benchmark workload (taps fetched, table look-ups,
+rays handed to the wave kernels) per hit ray."""
 import os
 import sys
 
@@ -21,9 +22,11 @@ ctx.set_sampling(bench.samples_for(n))
 ctx.set_mode(1)
 out = torch.empty(w * h * 4, dtype=torch.uint8, device="cuda")
 torch.cuda.synchronize()
-for step in (0, 30, 90, 200):
+for step in (0, 45, 90, 200):
     ctx.set_camera(*bench.orbit_camera(step))
-    st = ctx.render_device(w, h, out.data_ptr(), stats=True)
-    print(step, {k: st[k] for k in ("rays_hit", "samples_evaluated", "cells_read", "bricks_touched", "long_rays", "replay_rays")},
-          "taps/ray %.1f lookups/ray %.1f" % (st["samples_evaluated"] / st["rays_hit"], st["cells_read"] / st["rays_hit"]))
+    st = ctx.render_bands(w, h, 0, 1, ptr=out.data_ptr(), stats=True)
+    hit = max(1, st["rays_hit"])
+    print("step %3d  hit rays %d  taps/ray %.2f  look-ups/ray %.2f  long rays %.2f%%  replayed %.3f%%  bricks %d  kernel %.3f ms" % (
+        step, hit, st["samples_evaluated"] / hit, st["cells_read"] / hit, 100.0 * st["long_rays"] / hit,
+        100.0 * st["replay_rays"] / hit, st["bricks_touched"], st["kernel_ms"]))
 ctx.close()
