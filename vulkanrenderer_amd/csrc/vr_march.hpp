@@ -226,9 +226,9 @@ struct RayModel {
     float ax, ay, az;   // G(t) = a + t * b
     float bx, by, bz;
     // for counting taps while walking in the march direction (tap index changing by `dir` per step):
-    float ix, iy, iz;   // 1 / (dir * b), 0 where the ray does not move along the axis
-    float ux, uy, uz;   // 1 where the walk increases the coordinate (leaves through the upper face)
-    float sx, sy, sz;   // 1e9 where the ray does not move along the axis (never leaves), else 0
+    // 1 / (dir * b), 0 where the ray does not move along the axis (it never leaves through a face of that
+    // axis); positive where the walk increases the coordinate (it leaves through the upper face)
+    float ix, iy, iz;
     float margin;
     // Taps outside [t_stop, t_first] lie outside the bounding box of all occupied bricks (widened
     // by a voxel and a tap): they are in empty bricks and need no look at all.
@@ -252,12 +252,6 @@ __device__ __forceinline__ RayModel ray_model(const Ray &r, const VolumeView &v,
     m.ix = dx != 0.0f ? __builtin_amdgcn_rcpf(dx) : 0.0f;
     m.iy = dy != 0.0f ? __builtin_amdgcn_rcpf(dy) : 0.0f;
     m.iz = dz != 0.0f ? __builtin_amdgcn_rcpf(dz) : 0.0f;
-    m.ux = dx > 0.0f ? 1.0f : 0.0f;
-    m.uy = dy > 0.0f ? 1.0f : 0.0f;
-    m.uz = dz > 0.0f ? 1.0f : 0.0f;
-    m.sx = dx != 0.0f ? 0.0f : 1e9f;
-    m.sy = dy != 0.0f ? 0.0f : 1e9f;
-    m.sz = dz != 0.0f ? 0.0f : 1e9f;
     const float big = fmaxf(v.fx, fmaxf(v.fy, v.fz));
     m.margin = fmaxf(0.02f, big * 1e-5f);
     // clip the tap range against the box of occupied bricks: G(t) = a + t*b inside [L, U] per axis
@@ -462,11 +456,12 @@ __device__ __forceinline__ void clip_to_tile(RayModel &m, const Ray &r, float st
 
 // Steps (possibly fractional) until the model position leaves [lo, lo + extent) shrunk by the
 // margin along one axis; negative when it is not inside now.  Branch-free on purpose.
-__device__ __forceinline__ float axis_span(float g, float lo, float extent, float inv, float up, float still, float margin)
+__device__ __forceinline__ float axis_span(float g, float lo, float extent, float inv, float margin)
 {
     const float a = lo + margin, b = lo + extent - margin;
-    const float target = up != 0.0f ? b : a;
-    const float n = (target - g) * inv * 0.9999f + still;   // the reciprocal is good to 1 ulp: round the count down
+    const float target = inv > 0.0f ? b : a;
+    float n = (target - g) * inv * 0.9999f;   // the reciprocal is good to 1 ulp: round the count down
+    if (inv == 0.0f) n = 1e9f;                // not moving along this axis
     return (g >= a && g <= b) ? n : -1.0f;
 }
 
@@ -475,9 +470,9 @@ __device__ __forceinline__ float axis_span(float g, float lo, float extent, floa
 __device__ __forceinline__ int span_inside(float gx, float gy, float gz, int lox, int loy, int loz, float extent,
                                            const RayModel &m)
 {
-    float n = axis_span(gx, (float)lox, extent, m.ix, m.ux, m.sx, m.margin);
-    n = fminf(n, axis_span(gy, (float)loy, extent, m.iy, m.uy, m.sy, m.margin));
-    n = fminf(n, axis_span(gz, (float)loz, extent, m.iz, m.uz, m.sz, m.margin));
+    float n = axis_span(gx, (float)lox, extent, m.ix, m.margin);
+    n = fminf(n, axis_span(gy, (float)loy, extent, m.iy, m.margin));
+    n = fminf(n, axis_span(gz, (float)loz, extent, m.iz, m.margin));
     n = fminf(n, 1e9f);
     return n >= 0.0f ? 1 + (int)n : 0;
 }
