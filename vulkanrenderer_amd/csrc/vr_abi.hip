@@ -325,8 +325,9 @@ int refresh_occupancy(vr_ctx *ctx)
         hipLaunchKernelGGL((vr::k_classify_micro<uint16_t>), dim3(micro_blocks), dim3(256), 0, ctx->stream, (const uint16_t *)ctx->bricks,
                            ctx->empty[0], bricks, ctx->inv_hi, ctx->inv_lo, ctx->lut_info, ctx->micro);
     VR_HIP(ctx, hipMemsetAsync(ctx->d_occ_count, 0, sizeof(uint32_t), ctx->stream));
-    hipLaunchKernelGGL(vr::k_list_occupied, dim3((bricks + 255) / 256), dim3(256), 0, ctx->stream, ctx->empty[0], bricks, ctx->occ_list,
-                       ctx->d_occ_count);
+    const unsigned cubes4 = (unsigned)(((ctx->lx[0] + 3) / 4) * ((ctx->ly[0] + 3) / 4) * ((ctx->lz[0] + 3) / 4));
+    hipLaunchKernelGGL(vr::k_list_occupied, dim3((cubes4 + 3) / 4), dim3(256), 0, ctx->stream, ctx->empty[0], ctx->lx[0], ctx->ly[0],
+                       ctx->lz[0], ctx->occ_list, ctx->d_occ_count);
     VR_HIP(ctx, hipGetLastError());
     VR_HIP(ctx, hipMemcpyAsync(&ctx->occ_count, ctx->d_occ_count, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     VR_HIP(ctx, hipStreamSynchronize(ctx->stream));

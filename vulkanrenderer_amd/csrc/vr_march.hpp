@@ -319,11 +319,35 @@ __global__ __launch_bounds__(256) void k_occupied_bounds(const uint32_t *__restr
 #define VR_RANGE_SHIFT 3
 #endif
 constexpr int kRangeShift = VR_RANGE_SHIFT;
-__global__ __launch_bounds__(256) void k_list_occupied(const uint32_t *__restrict__ empty0, uint32_t bricks,
+// Lists the occupied bricks that have an empty (or no) neighbour across at least one face: only those
+// can be the first or last occupied brick of a ray, whatever the camera.  One wave looks at one cube of
+// 4^3 bricks and appends its finds in one piece, so bricks that are neighbours in space are neighbours
+// in the list (k_splat_bricks merges the ranges of a block's bricks per tile before it goes to memory).
+__global__ __launch_bounds__(256) void k_list_occupied(const uint32_t *__restrict__ empty0, int nbx, int nby, int nbz,
                                                       uint32_t *__restrict__ list, uint32_t *count)
 {
-    const uint32_t b = blockIdx.x * 256u + threadIdx.x;
-    if (b < bricks && !((empty0[b >> 5] >> (b & 31)) & 1u)) list[atomicAdd(count, 1u)] = b;
+    const int lane = threadIdx.x & 63;
+    const int gx_n = (nbx + 3) >> 2, gy_n = (nby + 3) >> 2, gz_n = (nbz + 3) >> 2;
+    const uint32_t group = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (group >= (uint32_t)(gx_n * gy_n * gz_n)) return;    // whole waves leave together
+    const int gx = (int)(group % (uint32_t)gx_n), gy = (int)((group / (uint32_t)gx_n) % (uint32_t)gy_n),
+              gz = (int)(group / (uint32_t)(gx_n * gy_n));
+    const int bx = gx * 4 + (lane & 3), by = gy * 4 + ((lane >> 2) & 3), bz = gz * 4 + (lane >> 4);
+    auto empty_at = [&](int x, int y, int z) -> bool {
+        if ((unsigned)x >= (unsigned)nbx || (unsigned)y >= (unsigned)nby || (unsigned)z >= (unsigned)nbz) return true;
+        const uint32_t b = (uint32_t)((z * nby + y) * nbx + x);
+        return (empty0[b >> 5] >> (b & 31)) & 1u;
+    };
+    bool keep = false;
+    if (bx < nbx && by < nby && bz < nbz && !empty_at(bx, by, bz))
+        keep = empty_at(bx - 1, by, bz) || empty_at(bx + 1, by, bz) || empty_at(bx, by - 1, bz) || empty_at(bx, by + 1, bz) ||
+               empty_at(bx, by, bz - 1) || empty_at(bx, by, bz + 1);
+    const unsigned long long mask = __ballot(keep);
+    if (mask == 0ull) return;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(count, (uint32_t)__popcll(mask));
+    base = (uint32_t)__shfl((int)base, 0);
+    if (keep) list[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)((bz * nby + by) * nbx + bx);
 }
 
 // Only bricks a ray can reach first or leave last have something to say.  A ray enters a brick through
@@ -338,13 +362,23 @@ __device__ __forceinline__ bool brick_is_empty(const VolumeView &vol, int bx, in
     return (vol.empty[0][b >> 5] >> (b & 31)) & 1u;
 }
 
-__global__ __launch_bounds__(256) void k_splat_bricks(VolumeView vol, FrameParams fp, const uint32_t *__restrict__ list,
-                                                     uint32_t count, uint2 *__restrict__ tiles, int tiles_x, int tiles_y,
-                                                     Counters *ctr)
+constexpr uint32_t kSplatSlots = 1024, kNoTile = 0xffffffffu;
+
+// Raises the range of one tile in global memory.  Both numbers only grow, so a range that would not
+// raise what the tile already holds has nothing to write; atomics on one address are served one
+// after the other.
+__device__ __forceinline__ void raise_tile(uint2 *t, uint32_t nb, uint32_t fb)
 {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= count) return;
-    const uint32_t brick = list[i];
+    if (nb != 0u && __atomic_load_n(&t->x, __ATOMIC_RELAXED) < nb) atomicMax(&t->x, nb);
+    if (fb != 0u && __atomic_load_n(&t->y, __ATOMIC_RELAXED) < fb) atomicMax(&t->y, fb);
+}
+
+// One brick of the list: the ranges of the tiles it covers go into the block's LDS table, or, where
+// the table is crowded, straight to global memory.
+__device__ __forceinline__ void splat_one(const VolumeView &vol, const FrameParams &fp, uint32_t brick, uint2 *__restrict__ tiles,
+                                          int tiles_x, int tiles_y, Counters *ctr, uint32_t *s_tile, uint32_t *s_near,
+                                          uint32_t *s_far)
+{
     const int bx = (int)(brick % (uint32_t)vol.nbx), by = (int)((brick / (uint32_t)vol.nbx) % (uint32_t)vol.nby),
               bz = (int)(brick / (uint32_t)(vol.nbx * vol.nby));
     // the eye in texel coordinates (inverse of the mapping below)
@@ -413,7 +447,7 @@ __global__ __launch_bounds__(256) void k_splat_bricks(VolumeView vol, FrameParam
         atomicOr(&ctr->clip_off, 1u);
         return;
     }
-    const uint32_t nb = 0x7f800000u - __float_as_uint(near), fb = __float_as_uint(far);
+    const uint32_t nb = front ? 0x7f800000u - __float_as_uint(near) : 0u, fb = back ? __float_as_uint(far) : 0u;
     for (int ty = ty0; ty <= ty1; ty++) {
         // only tiles this launch renders: inside the rectangle and, with a sort-first split, in one of
         // this part's 16-row bands
@@ -425,13 +459,44 @@ __global__ __launch_bounds__(256) void k_splat_bricks(VolumeView vol, FrameParam
         if (!mine) continue;
         for (int tx = tx0; tx <= tx1; tx++) {
             if (((tx + 1) << kRangeShift) <= fp.x0 || (tx << kRangeShift) >= fp.x1) continue;
-            // both numbers only grow, so a brick that would not raise what the tile already holds has
-            // nothing to write; most bricks lie behind the front-most ones of their tiles, and atomics
-            // on one address are served one after the other
-            uint2 *t = tiles + (size_t)ty * tiles_x + tx;
-            if (front && __atomic_load_n(&t->x, __ATOMIC_RELAXED) < nb) atomicMax(&t->x, nb);
-            if (back && __atomic_load_n(&t->y, __ATOMIC_RELAXED) < fb) atomicMax(&t->y, fb);
+            const uint32_t tile = (uint32_t)(ty * tiles_x + tx);
+            uint32_t slot = (tile * 2654435761u) >> 22;     // top 10 bits: kSplatSlots entries
+            bool placed = false;
+            for (int probe = 0; probe < 8 && !placed; probe++) {
+                const uint32_t held = atomicCAS(&s_tile[slot], kNoTile, tile);
+                if (held == kNoTile || held == tile) {
+                    if (nb != 0u) atomicMax(&s_near[slot], nb);
+                    if (fb != 0u) atomicMax(&s_far[slot], fb);
+                    placed = true;
+                }
+                slot = (slot + 1u) & (kSplatSlots - 1u);
+            }
+            if (!placed) raise_tile(tiles + tile, nb, fb);
         }
+    }
+}
+
+// Bricks next to each other in the list project onto the same few tiles, so a block first merges its
+// bricks' ranges per tile in LDS (a small open-addressing table keyed by the tile) and then raises
+// each tile of the table once in global memory: far fewer global atomics, which are the cost here.
+__global__ __launch_bounds__(256) void k_splat_bricks(VolumeView vol, FrameParams fp, const uint32_t *__restrict__ list,
+                                                     uint32_t count, uint2 *__restrict__ tiles, int tiles_x, int tiles_y,
+                                                     Counters *ctr)
+{
+    static_assert(kSplatSlots == 1024, "the hash keeps the top 10 bits");
+    __shared__ uint32_t s_tile[kSplatSlots], s_near[kSplatSlots], s_far[kSplatSlots];
+    for (uint32_t k = threadIdx.x; k < kSplatSlots; k += 256u) {
+        s_tile[k] = kNoTile;
+        s_near[k] = 0u;
+        s_far[k] = 0u;
+    }
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < count) splat_one(vol, fp, list[i], tiles, tiles_x, tiles_y, ctr, s_tile, s_near, s_far);
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < kSplatSlots; k += 256u) {
+        const uint32_t tile = s_tile[k];
+        if (tile != kNoTile) raise_tile(tiles + tile, s_near[k], s_far[k]);
     }
 }
 
