@@ -168,6 +168,13 @@ int vr_render_bands(vr_ctx *ctx, int width, int height, int part, int parts,
                     uint8_t *out, int out_is_device, vr_stats *stats);
 /* Rows a part owns (>= 0), or VR_ERR_ARG. */
 int vr_band_rows(int height, int part, int parts);
+/* Puts a frame together from the parts' band buffers after they have been gathered on one GPU (the
+ * gather itself is the caller's: one grouped send/recv or gather on its RCCL communicator):
+ * d_gathered holds part p's vr_render_bands output at byte offset p * part_stride_bytes
+ * (part_stride_bytes >= the largest part, part 0's).  Runs on the context's stream; d_frame gets
+ * width*height*4 bytes, the frame vr_render produces.  No counterpart in the reference (one GPU). */
+int vr_assemble_bands(vr_ctx *ctx, int width, int height, int parts, const uint8_t *d_gathered,
+                      uint64_t part_stride_bytes, uint8_t *d_frame);
 
 /* Device time (ms, HIP events on the context's stream) of the main march kernel of the most
  * recent frames, oldest first: at most `capacity` and at most the last 1024 frames.  Waits for

@@ -412,6 +412,31 @@ def test_sort_first_bands_tile_the_frame(ctx, vr, oracle, mode):
 
 # ---- histogram (prepareHistogramVolumeData, main.cpp:166-181) -----------------------------------
 
+def test_assemble_gathered_bands(ctx, oracle, torch):
+    """vr_assemble_bands: the parts' band buffers, laid out as a gather leaves them, give the whole frame."""
+    import vulkanrenderer_amd as vr
+    ctx.upload_volume(oracle.phantom(48, np.uint16))
+    ctx.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+    ctx.set_camera(*cf.CAMERAS["h30_v20"])
+    ctx.set_sampling(120)
+    ctx.set_mode(1)
+    w, h = 150, 117           # 8 bands, the last one short
+    whole = ctx.render(w, h)
+    for parts in (1, 3, 8, 11):
+        stride = vr.band_rows(h, 0, parts) * w * 4 + 64       # some padding between the parts
+        gathered = torch.zeros(parts * stride, dtype=torch.uint8, device="cuda")
+        frame = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        for p in range(parts):
+            if vr.band_rows(h, p, parts) > 0:
+                ctx.render_bands(w, h, p, parts, ptr=gathered.data_ptr() + p * stride)
+        ctx.assemble_bands(w, h, parts, gathered.data_ptr(), stride, frame.data_ptr())
+        ctx.synchronize()
+        assert np.array_equal(frame.cpu().numpy(), whole), parts
+    with pytest.raises(vr.VrError):
+        ctx.assemble_bands(w, h, 3, gathered.data_ptr(), 16, frame.data_ptr())
+
+
 @pytest.mark.parametrize("dtype,shape", [(np.uint8, (20, 33, 41)), (np.uint16, (17, 24, 30)), (np.uint16, (1, 1, 1))])
 def test_histogram_bit_exact(ctx, oracle, dtype, shape):
     rng = np.random.default_rng(21)

@@ -1044,6 +1044,22 @@ int vr_band_rows(int height, int part, int parts)
     return rows_of_part(height, part, parts);
 }
 
+int vr_assemble_bands(vr_ctx *ctx, int width, int height, int parts, const uint8_t *d_gathered, uint64_t part_stride_bytes,
+                      uint8_t *d_frame)
+{
+    if (!ctx || !d_gathered || !d_frame) return fail(ctx, VR_ERR_ARG, "null argument");
+    if (width < 1 || height < 1 || width > 65536 || height > 65536 || parts < 1) return fail(ctx, VR_ERR_ARG, "bad image size or part count");
+    if (part_stride_bytes % 4 != 0 || part_stride_bytes < (uint64_t)rows_of_part(height, 0, parts) * (uint64_t)width * 4ull)
+        return fail(ctx, VR_ERR_ARG, "part stride smaller than the largest part or not a multiple of 4");
+    if (int rc = bind(ctx)) return rc;
+    const size_t pixels = (size_t)width * (size_t)height;
+    hipLaunchKernelGGL(vr::k_assemble_bands, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<const uint32_t *>(d_gathered), (size_t)(part_stride_bytes / 4), parts, width, height,
+                       reinterpret_cast<uint32_t *>(d_frame));
+    VR_HIP(ctx, hipGetLastError());
+    return VR_OK;
+}
+
 int vr_count_hit_rays(vr_ctx *ctx, int width, int height, int x0, int y0, int x1, int y1, uint64_t *hits)
 {
     if (!ctx || !hits) return fail(ctx, VR_ERR_ARG, "null argument");

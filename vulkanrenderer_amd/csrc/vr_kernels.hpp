@@ -403,6 +403,19 @@ __device__ __forceinline__ void pixel_of_index(const FrameParams &fp, uint32_t o
 // channel.  Segments are applied in order (a later segment overwrites the pixel it shares with
 // the previous one, main.cpp:660-681); inside a segment the written pixels are distinct, so the
 // lanes of a wave can take one k each.  Table entries no segment covers keep their old value.
+// Sort-first assembly: `src` holds the parts' dense band buffers one after the other, `stride` pixels
+// apart; row y of the frame is row (y / 16 / parts) * 16 + y % 16 of part (y / 16) % parts.
+__global__ __launch_bounds__(256) void k_assemble_bands(const uint32_t *__restrict__ src, size_t stride, int parts, int width,
+                                                       int height, uint32_t *__restrict__ dst)
+{
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= (size_t)width * (size_t)height) return;
+    const int y = (int)(i / (size_t)width), x = (int)(i % (size_t)width);
+    const int band = y >> 4;
+    const size_t row = (size_t)(band / parts) * 16u + (size_t)(y & 15);
+    dst[i] = src[(size_t)(band % parts) * stride + row * (size_t)width + (size_t)x];
+}
+
 struct CtrlPt {
     float x, intensity;
 };
