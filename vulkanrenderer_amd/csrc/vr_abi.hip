@@ -90,6 +90,7 @@ struct vr_ctx {
     bool shading = false;
     float scene[4] = {1.0f, 1.0f, 1.0f, 100.0f};   // main.cpp:90-98
     int pipeline_depth = 1;
+    int tail_blocks = 8192;   // grid of the wave-per-ray kernels: more, shorter queues per wave even out the rays' lengths (VR_TAIL_BLOCKS)
     hipStream_t tail_stream = nullptr;
     hipEvent_t main_done[2] = {nullptr, nullptr}, tail_done[2] = {nullptr, nullptr}, frame_done = nullptr;
     bool tail_busy[2] = {false, false};
@@ -393,7 +394,7 @@ void launch_frame_as(vr_ctx *ctx, const vr::FrameParams &fp, uint32_t *d_out, co
             tiles = fb.tiles;
             (void)hipEventRecord(ctx->ring_a[slot], s);   // the ring times the march kernel alone
         }
-        const dim3 replay_grid(2048);  // 8192 waves, one ray each per pass
+        const dim3 replay_grid((unsigned)ctx->tail_blocks);  // 4 waves each, one ray per wave and pass
         hipLaunchKernelGGL((vr::k_march_fast<T, STATS, SHADE>), grid, block, 0, s, vol, fp, lut, border, ctx->lut_info, d_out, fb.counters, ctx->touched, fb.queue, fb.long_queue, ctx->lane_budget, tiles, tiles_x);
         (void)hipEventRecord(ctx->ring_b[slot], s);
         hipStream_t ts = fb.tail;
@@ -446,6 +447,7 @@ int vr_create(int device, vr_ctx **out)
     if (const char *e = std::getenv("VR_TILE_CLIP")) ctx->tile_clip = std::atoi(e) != 0;
     if (const char *e = std::getenv("VR_LANE_BUDGET")) ctx->lane_budget = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("VR_PARTIAL_BUDGET")) ctx->partial_budget = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("VR_TAIL_BLOCKS")) ctx->tail_blocks = std::max(64, std::min(65536, std::atoi(e)));
     if (const char *e = std::getenv("VR_WAVES_PER_BLOCK")) ctx->waves_per_block = std::max(1, std::min(4, std::atoi(e)));
     ctx->ring_a.resize(vr_ctx::kRing, nullptr);
     ctx->ring_b.resize(vr_ctx::kRing, nullptr);
