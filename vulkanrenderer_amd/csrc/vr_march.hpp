@@ -1253,7 +1253,14 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
             F1 = __builtin_fma(Tr, (double)tf.y, F1);
             F2 = __builtin_fma(Tr, (double)tf.z, F2);
             Tr = 0.0;
-            decided = fast_ok && try_decide(0);
+            if (fast_ok && S == 0.0f) {
+                // no tap in front of it had alpha != 0: every blend was an identity and the shader's colour
+                // is this tap's, bit for bit (most pixels of tiles no occupied brick projects into)
+                rgba = pack_rgba8(tf.x, tf.y, tf.z);
+                decided = true;
+            } else {
+                decided = fast_ok && try_decide(0);
+            }
             if (!decided) queue[atomicAdd(&ctr->replay_count, 1u)] = pixel_id;
         }
         if (!r.hit || decided) out[pixel_id] = rgba;
