@@ -1010,8 +1010,19 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
 
     const int last = fp.samples + 1;
     const float step = (r.tmax - r.tmin) / (float)(uint32_t)last;
-    RayModel rm = ray_model(r, vol, step, -1.0f);
-    if (in_rect) clip_to_tile(rm, r, step, tiles, tiles_x, px, py, ctr);
+    RayModel rm;
+    // more than half of the tiles of a typical frame have no occupied brick behind them: their rays need
+    // no line model, only the back-most tap
+    const bool nothing = in_rect && tiles && !ctr->clip_off && step > 0.0f &&
+                         tiles[(size_t)(py >> kRangeShift) * tiles_x + (px >> kRangeShift)].y == 0u;
+    if (nothing) {
+        rm = RayModel{};
+        rm.t_first = 0;
+        rm.t_stop = 0x7fffffff;
+    } else {
+        rm = ray_model(r, vol, step, -1.0f);
+        if (in_rect) clip_to_tile(rm, r, step, tiles, tiles_x, px, py, ctr);
+    }
 
     double F0 = 0.0, F1 = 0.0, F2 = 0.0, Tr = 1.0;
     float S = 0.0f;
