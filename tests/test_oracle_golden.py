@@ -59,7 +59,7 @@ def test_camera_matches_golden(oracle, golden):
 
 
 def test_camera_default_pose(oracle):
-    # side (1,0,0) up (0,0,1) forward (0,1,0) location (0,-5,-.5), height 4.5
+    # default pose (main.cpp:68-77,182-202): side (1,0,0) up (0,0,1) forward (0,1,0) location (0,-5,-.5), height 4.5
     vp, m = oracle.camera(0.0, 0.0, 1280, 720)
     vp = vp.reshape(5, 4)
     assert vp[0, 0] == 4.5
