@@ -24,17 +24,21 @@ ctx.set_mode(1)
 out = torch.empty(w * h * 4, dtype=torch.uint8, device="cuda")
 torch.cuda.synchronize()
 frames = 36
-for parts in (1, 2, 4, 8):
+out2 = torch.empty(w * h * 4, dtype=torch.uint8, device="cuda")
+for depth in (1, 2):
+  ctx.set_pipeline(depth)
+  print("frames in flight:", depth, flush=True)
+  for parts in (1, 2, 4, 8):
     worst = 0.0
     for part in range(parts):
         for i in range(2):
             ctx.set_camera(*bench.orbit_camera(i))
-            ctx.render_bands(w, h, part, parts, ptr=out.data_ptr())
+            ctx.render_bands(w, h, part, parts, ptr=(out, out2)[i & 1].data_ptr())
         ctx.synchronize()
         t0 = time.perf_counter()
         for i in range(frames):
             ctx.set_camera(*bench.orbit_camera(i * 10))
-            ctx.render_bands(w, h, part, parts, ptr=out.data_ptr())
+            ctx.render_bands(w, h, part, parts, ptr=(out, out2)[i & 1].data_ptr())
         ctx.synchronize()
         worst = max(worst, (time.perf_counter() - t0) / frames * 1e3)
     print("parts %d: slowest part %.3f ms per frame" % (parts, worst), flush=True)
