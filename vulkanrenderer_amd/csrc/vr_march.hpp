@@ -697,16 +697,25 @@ __global__ __launch_bounds__(256) void k_march_exact(VolumeView vol, FrameParams
 // See k_march_fast for the argument.  decide() returns true and the final bytes when, for all
 // three channels, both ends of the interval that must contain the shader's float result convert to
 // the same unorm8 value.
+#ifndef VR_DECIDE_GATE
+#define VR_DECIDE_GATE (1.0f / 255.0f)
+#endif
 struct Decider {
     float cmin[3], cmax[3], kappa[3];
+    // Transmittance below which a decision is possible at all: both interval ends can only convert to
+    // the same byte if they are less than 1/255 apart, and the interval is at least tr * (cmax - cmin) wide.
+    float tr_gate;
     bool ok;
     __device__ explicit Decider(const LutInfo *info)
     {
+        float range = 0.0f;
         for (int c = 0; c < 3; c++) {
             cmin[c] = info->cmin[c];
             cmax[c] = info->cmax[c];
             kappa[c] = info->kappa[c];
+            range = fmaxf(range, cmax[c] - cmin[c]);
         }
+        tr_gate = range > 0.0f ? fminf(1.0f, (VR_DECIDE_GATE) / range) : 1.0f;
         ok = info->fast_ok != 0;
     }
     __device__ __forceinline__ bool decide(double F0, double F1, double F2, double tr, float S, int taps_left, uint32_t &rgba) const
@@ -1226,7 +1235,7 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
         }
         // 3. early termination, tested every few rounds for all lanes at once: the test costs about as
         //    much as half a tap and the whole wave pays for it whenever a single lane runs it
-        if (!PARTIAL && (round & (kDecideEvery - 1)) == kDecideEvery - 1 && fast_ok && marching && Tr < 0.03125) {
+        if (!PARTIAL && (round & (kDecideEvery - 1)) == kDecideEvery - 1 && fast_ok && marching && Tr < (double)dec.tr_gate) {
             if (try_decide(t + 1)) {     // taps t .. 0 are still to come
                 decided = true;
                 marching = false;
@@ -1455,7 +1464,7 @@ __device__ __forceinline__ bool continue_ray(const VolumeView &vol, const FrameP
             Tr = Tr * part.tr;
         }
         t -= 64 * kLongTaps;
-        if (!PARTIAL && dec.ok && Tr < 0.03125) decided = dec.decide(F0, F1, F2, Tr, S, (t > 0 ? t : 0) + 1, rgba);
+        if (!PARTIAL && dec.ok && Tr < (double)dec.tr_gate) decided = dec.decide(F0, F1, F2, Tr, S, (t > 0 ? t : 0) + 1, rgba);
     }
     if (PARTIAL) {
         float res[kPartial];
