@@ -128,6 +128,11 @@ def main():
     ctx.set_mode(mode)
     if args.shading:
         ctx.set_shading(True)
+    lane_budget = None
+    if mode == vr.MODE_FAST and not os.environ.get("VR_LANE_BUDGET"):
+        # part of the set-up: the library measures its one tuning parameter on a view of the orbit
+        ctx.set_camera(*orbit_camera(45))
+        lane_budget = ctx.tune(w, h, rank if world > 1 else 0, world if world > 1 else 1)
     t_setup = time.perf_counter() - t_setup
 
     sf = SortFirstFrame(w, h, rank, world, device, host_staging=backend != "nccl")
@@ -247,6 +252,7 @@ def main():
                 "parallelism": "sort-first x%d (16-row bands, replicated volume, RCCL gather)" % world if world > 1 else "single GPU",
                 "frames_in_flight": 2,
                 "shading": bool(args.shading),
+                "lane_budget": lane_budget,
                 "setup_s": round(t_setup, 2),
             },
             "roofline": {

@@ -181,6 +181,12 @@ int vr_assemble_bands(vr_ctx *ctx, int width, int height, int parts, const uint8
  * the stream.  Measurement aid (the reference only shows whole-loop FPS in the window title,
  * Source/VulkanApplication.cpp:617-620). */
 int vr_march_kernel_times(vr_ctx *ctx, float *ms, int capacity, int *count);
+/* Picks the fast mode's one tuning parameter by measurement: renders the current camera's frame (or
+ * the sort-first share part/parts of it) a few times for each candidate of the per-lane work budget
+ * -- how long a lane marches its ray before a whole wave takes it over -- and keeps the fastest.
+ * Frames are identical for every value; only the time changes with volume, table and image size.
+ * chosen_budget may be NULL.  No counterpart in the reference. */
+int vr_tune(vr_ctx *ctx, int width, int height, int part, int parts, int *chosen_budget);
 
 /* Number of rays of the rectangle that hit the volume box; the reference marches
  * samples_per_ray + 2 taps on each of them (VolumeRendering.comp:180-184). */

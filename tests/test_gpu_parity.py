@@ -412,6 +412,22 @@ def test_sort_first_bands_tile_the_frame(ctx, vr, oracle, mode):
 
 # ---- histogram (prepareHistogramVolumeData, main.cpp:166-181) -----------------------------------
 
+def test_tune_keeps_the_frame(ctx, oracle):
+    """vr_tune picks the per-lane work budget by timing; the frame does not depend on it."""
+    ctx.upload_volume(oracle.phantom(64, np.uint16))
+    ctx.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+    ctx.set_camera(*cf.CAMERAS["h30_v20"])
+    ctx.set_sampling(250)
+    ctx.set_mode(0)
+    ref = ctx.render(160, 120)
+    assert ctx.tune(160, 120) in (64, 80, 96, 112, 128)
+    assert np.array_equal(ctx.render(160, 120), ref)          # tune leaves mode and pipeline as they were
+    ctx.set_mode(1)
+    assert np.array_equal(ctx.render(160, 120), ref)
+    assert ctx.tune(160, 120, 1, 3) in (64, 80, 96, 112, 128)
+    assert np.array_equal(ctx.render(160, 120), ref)
+
+
 def test_assemble_gathered_bands(ctx, oracle, torch):
     """vr_assemble_bands: the parts' band buffers, laid out as a gather leaves them, give the whole frame."""
     import vulkanrenderer_amd as vr

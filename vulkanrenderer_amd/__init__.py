@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     "vr_control_point_intensity", "vr_set_camera", "vr_set_camera_raw", "vr_get_camera",
     "vr_camera_uniforms",
     "vr_set_sampling", "vr_set_mode", "vr_set_shading", "vr_render", "vr_render_rect", "vr_render_bands", "vr_assemble_bands",
-    "vr_band_rows", "vr_set_pipeline", "vr_wait_frame", "vr_march_kernel_times", "vr_count_hit_rays",
+    "vr_band_rows", "vr_set_pipeline", "vr_wait_frame", "vr_march_kernel_times", "vr_tune", "vr_count_hit_rays",
     "vr_phantom_generate_device", "vr_phantom_generate_box_device",
     "vr_brick_grid", "vr_subvolume_voxels", "vr_upload_subvolume_device", "vr_render_partial",
     "vr_composite_pair", "vr_composite_ordered", "vr_decide_partials", "vr_chain_stage",
@@ -102,6 +102,7 @@ def lib():
     L.vr_set_pipeline.argtypes = [vp, C.c_int]
     L.vr_wait_frame.argtypes = [vp, vp]
     L.vr_band_rows.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.vr_tune.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
     L.vr_assemble_bands.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]
     L.vr_march_kernel_times.argtypes = [vp, fp, C.c_int, C.POINTER(C.c_int)]
     L.vr_count_hit_rays.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
@@ -310,6 +311,12 @@ class VolumeRenderer:
         self._check(lib().vr_render_rect(self._h, width, height, x0, y0, x1, y1, out.ctypes.data, 0,
                                          C.byref(st) if stats else None))
         return (out, st.as_dict()) if stats else out
+
+    def tune(self, width, height, part=0, parts=1):
+        """Measures and keeps the fastest per-lane work budget for the current volume, table and camera."""
+        chosen = C.c_int()
+        self._check(lib().vr_tune(self._h, width, height, part, parts, C.byref(chosen)))
+        return chosen.value
 
     def assemble_bands(self, width, height, parts, gathered_ptr, part_stride_bytes, frame_ptr):
         """Frame from the parts' gathered band buffers (device pointers); asynchronous on the context's stream."""

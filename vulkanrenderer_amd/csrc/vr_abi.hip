@@ -1028,6 +1028,48 @@ int vr_march_kernel_times(vr_ctx *ctx, float *ms, int capacity, int *count)
     return VR_OK;
 }
 
+int vr_tune(vr_ctx *ctx, int width, int height, int part, int parts, int *chosen_budget)
+{
+    if (!ctx) return VR_ERR_ARG;
+    if (!ctx->bricks) return fail(ctx, VR_ERR_STATE, "no volume uploaded");
+    if (ctx->sub) return fail(ctx, VR_ERR_STATE, "the context holds a sub-volume");
+    if (parts < 1 || part < 0 || part >= parts) return fail(ctx, VR_ERR_ARG, "bad part");
+    if (int rc = bind(ctx)) return rc;
+    const size_t pixels = (size_t)width * (size_t)std::max(1, rows_of_part(height, part, parts));
+    uint8_t *scratch = nullptr;
+    VR_HIP(ctx, hipMalloc(&scratch, pixels * 4));
+    const int mode = ctx->mode, depth = ctx->pipeline_depth, before = ctx->lane_budget;
+    ctx->mode = VR_MODE_FAST;
+    ctx->pipeline_depth = 1;
+    // How long a lane stays with its ray before it hands it to a wave of its own: the best value
+    // depends on how the rays' lengths are spread, i.e. on volume, table, image size and share.
+    const int candidates[] = {64, 80, 96, 112, 128};
+    int best = before, rc = VR_OK;
+    float best_ms = 3.0e38f;
+    for (int budget : candidates) {
+        ctx->lane_budget = budget;
+        float fastest = 3.0e38f;
+        for (int rep = 0; rep < 3 && rc == VR_OK; rep++) {      // the first one also warms the caches
+            rc = render_impl(ctx, width, height, 0, 0, width, height, part, parts, scratch, 1, nullptr);
+            if (rc == VR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, VR_ERR_HIP, "synchronize failed");
+            float ms = 0.0f;
+            if (rc == VR_OK && hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) != hipSuccess) rc = fail(ctx, VR_ERR_HIP, "event time failed");
+            if (rep > 0 && ms < fastest) fastest = ms;
+        }
+        if (rc != VR_OK) break;
+        if (fastest < best_ms) {
+            best_ms = fastest;
+            best = budget;
+        }
+    }
+    ctx->lane_budget = rc == VR_OK ? best : before;
+    ctx->mode = mode;
+    ctx->pipeline_depth = depth;
+    (void)hipFree(scratch);
+    if (rc == VR_OK && chosen_budget) *chosen_budget = best;
+    return rc;
+}
+
 #ifdef VR_DIAG
 // diagnostic build only (make diag): device buffer of 4 x uint64 per wave of the next fast march
 int vr_diag_set_timeline(vr_ctx *ctx, void *d_buffer)
