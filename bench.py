@@ -73,6 +73,9 @@ def main():
     ap.add_argument("--mode", choices=("fast", "reference", "reference_skip"), default="fast")
     ap.add_argument("--stats-frames", type=int, default=12, help="frames measured with counters for the roofline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tune", action="store_true",
+                    help="let the library pick its per-lane work budget by timing one view (vr_tune); the default "
+                         "value is the one measured best for the default workload")
     ap.add_argument("--shading", action="store_true",
                     help="switch on the shader's commented-out lighting (not the headline workload: the reference renders without it)")
     args = ap.parse_args()
@@ -129,7 +132,7 @@ def main():
     if args.shading:
         ctx.set_shading(True)
     lane_budget = None
-    if mode == vr.MODE_FAST and not os.environ.get("VR_LANE_BUDGET"):
+    if args.tune and mode == vr.MODE_FAST:
         # part of the set-up: the library measures its one tuning parameter on a view of the orbit
         ctx.set_camera(*orbit_camera(45))
         lane_budget = ctx.tune(w, h, rank if world > 1 else 0, world if world > 1 else 1)

@@ -702,8 +702,9 @@ __global__ __launch_bounds__(256) void k_march_exact(VolumeView vol, FrameParams
 #endif
 struct Decider {
     float cmin[3], cmax[3], kappa[3];
-    // Transmittance below which a decision is possible at all: both interval ends can only convert to
-    // the same byte if they are less than 1/255 apart, and the interval is at least tr * (cmax - cmin) wide.
+    // Transmittance below which the decision test is tried.  With all colours inside [0,1] both interval
+    // ends can only convert to the same byte if they are less than 1/255 apart, and the interval is at
+    // least tr * (cmax - cmin) wide.
     float tr_gate;
     bool ok;
     __device__ explicit Decider(const LutInfo *info)
@@ -716,6 +717,10 @@ struct Decider {
             range = fmaxf(range, cmax[c] - cmin[c]);
         }
         tr_gate = range > 0.0f ? fminf(1.0f, (VR_DECIDE_GATE) / range) : 1.0f;
+        // colours outside [0,1] (a table with such entries, or the local illumination): an interval of any
+        // width is decided once it lies wholly above 1 or below 0, so the test is worth trying earlier
+        for (int c = 0; c < 3; c++)
+            if (cmax[c] > 1.0f || cmin[c] < 0.0f) tr_gate = fmaxf(tr_gate, 0.03125f);
         ok = info->fast_ok != 0;
     }
     __device__ __forceinline__ bool decide(double F0, double F1, double F2, double tr, float S, int taps_left, uint32_t &rgba) const
