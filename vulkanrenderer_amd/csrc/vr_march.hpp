@@ -1111,9 +1111,17 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
         while (marching && !have && work < budget) {
             if (t < t_stop) { marching = false; break; }
             work++;
-            const float ft = (float)t;
-            const float gx = __builtin_fmaf(ft, rm.bx, rm.ax), gy = __builtin_fmaf(ft, rm.by, rm.ay),
-                        gz = __builtin_fmaf(ft, rm.bz, rm.az);
+            // position of tap t in the padded texel grid for the span counts below: the line model's, or,
+            // when every pass takes the exact position anyway, that one (it differs from the model by
+            // rounding only, which the margin covers just the same, and the model's six coefficients
+            // need not stay in registers)
+            float gx = 0.0f, gy = 0.0f, gz = 0.0f;
+            if (model_cells) {
+                const float ft = (float)t;
+                gx = __builtin_fmaf(ft, rm.bx, rm.ax);
+                gy = __builtin_fmaf(ft, rm.by, rm.ay);
+                gz = __builtin_fmaf(ft, rm.bz, rm.az);
+            }
             if (in_air) {
 #ifdef VR_DIAG
                 diag_model++;
@@ -1133,7 +1141,13 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
                         continue;
                     }
                 } else {
-                    c = tap_cell(tap_position(r, vol, step, t), vol);
+                    const Tap p = tap_position(r, vol, step, t);
+                    c = tap_cell(p, vol);
+                    if (!model_cells) {
+                        gx = p.x + (float)kPad;
+                        gy = p.y + (float)kPad;
+                        gz = p.z + (float)kPad;
+                    }
                 }
             }
             brick = brick_of(c, vol);
