@@ -235,6 +235,27 @@ struct RayModel {
     int t_first, t_stop;
 };
 
+// The line itself, without the clip against the occupied bricks (t_first, t_stop left open).
+__device__ __forceinline__ RayModel ray_line(const Ray &r, const VolumeView &v, float step, float dir)
+{
+    RayModel m;
+    m.ax = (r.o[0] + r.tmax * r.d[0] + 0.5f) * v.fx - 0.5f + (float)(kPad - v.ox);
+    m.ay = (r.o[1] + r.tmax * r.d[1] + 0.5f) * v.fy - 0.5f + (float)(kPad - v.oy);
+    m.az = -(r.o[2] + r.tmax * r.d[2]) * v.fz - 0.5f + (float)(kPad - v.oz);
+    m.bx = -(step * r.d[0]) * v.fx;
+    m.by = -(step * r.d[1]) * v.fy;
+    m.bz = (step * r.d[2]) * v.fz;
+    const float dx = dir * m.bx, dy = dir * m.by, dz = dir * m.bz;
+    m.ix = dx != 0.0f ? __builtin_amdgcn_rcpf(dx) : 0.0f;
+    m.iy = dy != 0.0f ? __builtin_amdgcn_rcpf(dy) : 0.0f;
+    m.iz = dz != 0.0f ? __builtin_amdgcn_rcpf(dz) : 0.0f;
+    const float big = fmaxf(v.fx, fmaxf(v.fy, v.fz));
+    m.margin = fmaxf(0.02f, big * 1e-5f);
+    m.t_first = 0x7fffffff;
+    m.t_stop = 1;
+    return m;
+}
+
 __device__ __forceinline__ RayModel ray_model(const Ray &r, const VolumeView &v, float step, float dir)
 {
     RayModel m;
@@ -917,8 +938,11 @@ struct LongRay {
     uint32_t pixel_id;
     int t;        // next tap to visit (>= 1)
     float S;
-    float pad_;
+    int t_stop;   // taps below it (the back tap aside) cannot matter: the lane march's clipped value
     double F0, F1, F2, Tr;
+    // the ray as the lane march computed it, so that the wave that takes over need not repeat the
+    // divisions of the slab test, the clip against the occupied bricks and the tile look-up
+    float d[3], tmax, step, pad_;
 };
 
 // Fetch rounds a lane spends on its ray before it hands the rest over: bounds the serial,
@@ -1268,8 +1292,10 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
     if (marching) {
         // out of budget with taps left: the next pass continues this ray
         LongRay e;
-        e.pixel_id = pixel_id; e.t = t; e.S = S; e.pad_ = 0.0f;
+        e.pixel_id = pixel_id; e.t = t; e.S = S; e.t_stop = t_stop;
         e.F0 = F0; e.F1 = F1; e.F2 = F2; e.Tr = Tr;
+        e.d[0] = r.d[0]; e.d[1] = r.d[1]; e.d[2] = r.d[2];
+        e.tmax = r.tmax; e.step = step; e.pad_ = 0.0f;
         next_queue[atomicAdd(next_count, 1u)] = e;
     } else if (PARTIAL) {
         if (in_rect) {
@@ -1394,20 +1420,22 @@ __device__ __forceinline__ bool continue_ray(const VolumeView &vol, const FrameP
                                              float *__restrict__ partial_out = nullptr)
 {
     const int lane = threadIdx.x & 63;
-    int px, py;
-    pixel_of_index(fp, e.pixel_id, px, py);
-    const Ray r = make_ray(fp, px, py);          // identical in every lane
-    const int last = fp.samples + 1;
-    const float step = (r.tmax - r.tmin) / (float)(uint32_t)last;
-    RayModel rm = ray_model(r, vol, step, -1.0f);
-    clip_to_tile(rm, r, step, tiles, tiles_x, px, py, ctr);
+    // the ray and its clipped tap range as the lane march left them (identical in every lane)
+    Ray r;
+    r.o[0] = fp.loc[0]; r.o[1] = fp.loc[1]; r.o[2] = fp.loc[2];
+    r.d[0] = e.d[0]; r.d[1] = e.d[1]; r.d[2] = e.d[2];
+    r.tmax = e.tmax;
+    r.tmin = 0.0f;      // not needed any more: the step is carried
+    r.hit = true;
+    const float step = e.step;
+    RayModel rm = ray_line(r, vol, step, -1.0f);
+    rm.t_stop = e.t_stop;
     double F0 = e.F0, F1 = e.F1, F2 = e.F2, Tr = e.Tr;
     float S = e.S;
     int t = e.t;
     bool decided = false;
     rgba = 0xff000000u;
     unsigned long long evaluated = 0;
-    if (t > rm.t_first) t = rm.t_first;
     while (t >= rm.t_stop && !decided && !(PARTIAL && Tr < kTrCut)) {
         const int n = empty_span(vol, rm, t);   // wave-uniform
         if (n > 0) {
