@@ -279,7 +279,7 @@ int ingest_device(vr_ctx *ctx, T *d_raw, int nx, int ny, int nz, float max_value
     VR_HIP(ctx, hipMalloc(&ctx->skip, ((ctx->brick_count + 15) / 16) * sizeof(uint32_t)));
     VR_HIP(ctx, hipMalloc(&ctx->occ_list, ctx->brick_count * sizeof(uint32_t)));
     ctx->occupancy_dirty = true;
-    const unsigned brick_blocks = (unsigned)std::min<size_t>(ctx->brick_count, 1u << 20);
+    const unsigned brick_blocks = (unsigned)std::min<size_t>((ctx->brick_count + 3) / 4, 1u << 20);   // four waves, a brick each
     hipLaunchKernelGGL((vr::k_build_bricks<T>), dim3(brick_blocks), dim3(256), 0, ctx->stream, (const T *)d_raw,
                        (T *)ctx->bricks, ctx->cells, nx, ny, nz, ctx->nbx, ctx->nby, (uint32_t)ctx->brick_count, src);
     VR_HIP(ctx, hipGetLastError());

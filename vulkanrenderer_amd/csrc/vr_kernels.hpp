@@ -493,43 +493,40 @@ __global__ __launch_bounds__(256) void k_build_bricks(const T *__restrict__ raw,
                                                      uint32_t *__restrict__ cells, int nx, int ny, int nz,
                                                      int nbx, int nby, uint32_t brick_count, BrickSource src)
 {
-    __shared__ uint32_t s_mn[4], s_mx[4];
-    // a launch holds at most 2^32 - 1 threads, fewer than a 2048^3 volume has bricks x 256
-    for (uint32_t brick = blockIdx.x; brick < brick_count; brick += gridDim.x) {
-    const int bx = brick % nbx, by = (brick / nbx) % nby, bz = brick / (nbx * nby);
-    T *dst = bricks + (size_t)brick * kBrickElems;
-    uint32_t mn = 0xffffffffu, mx = 0;
-    for (int e = threadIdx.x; e < kBrickElems; e += 256) {
-        uint32_t v = 0;
-        if (e < kRow * kRow * kRow) {
+    // One wave per brick and pass: each lane gathers 12 of the brick's 768 elements (all loads in flight
+    // together), writes them, and the wave folds minimum and maximum with shuffles -- no barrier, no LDS.
+    const int lane = threadIdx.x & 63;
+    const uint32_t waves = gridDim.x * 4u;
+    for (uint32_t brick = blockIdx.x * 4u + (threadIdx.x >> 6); brick < brick_count; brick += waves) {
+        const int bx = brick % nbx, by = (brick / nbx) % nby, bz = brick / (nbx * nby);
+        const int x0 = (bx + src.b0[0]) * kBrick - kPad, y0 = (by + src.b0[1]) * kBrick - kPad, z0 = (bz + src.b0[2]) * kBrick - kPad;
+        T *dst = bricks + (size_t)brick * kBrickElems;
+        uint32_t v[kBrickElems / 64];
+#pragma unroll
+        for (int k = 0; k < kBrickElems / 64; k++) {
+            const int e = k * 64 + lane;
             const int lx = e % kRow, ly = (e / kRow) % kRow, lz = e / kSlice;
-            const int ix = (bx + src.b0[0]) * kBrick + lx - kPad, iy = (by + src.b0[1]) * kBrick + ly - kPad,
-                      iz = (bz + src.b0[2]) * kBrick + lz - kPad;
-            if ((unsigned)ix < (unsigned)nx && (unsigned)iy < (unsigned)ny && (unsigned)iz < (unsigned)nz)
-                v = raw[((size_t)(iz - src.v0[2]) * src.ry + (iy - src.v0[1])) * src.rx + (ix - src.v0[0])];
-            mn = v < mn ? v : mn;
-            mx = v > mx ? v : mx;
+            const int ix = x0 + lx, iy = y0 + ly, iz = z0 + lz;
+            v[k] = 0;
+            if (e < kRow * kRow * kRow && (unsigned)ix < (unsigned)nx && (unsigned)iy < (unsigned)ny && (unsigned)iz < (unsigned)nz)
+                v[k] = raw[((size_t)(iz - src.v0[2]) * src.ry + (iy - src.v0[1])) * src.rx + (ix - src.v0[0])];
         }
-        dst[e] = (T)v;
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        const uint32_t a = __shfl_xor(mn, o), b = __shfl_xor(mx, o);
-        mn = a < mn ? a : mn;
-        mx = b > mx ? b : mx;
-    }
-    if ((threadIdx.x & 63) == 0) {
-        s_mn[threadIdx.x >> 6] = mn;
-        s_mx[threadIdx.x >> 6] = mx;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; w++) {
-            mn = s_mn[w] < mn ? s_mn[w] : mn;
-            mx = s_mx[w] > mx ? s_mx[w] : mx;
+        uint32_t mn = 0xffffffffu, mx = 0;
+#pragma unroll
+        for (int k = 0; k < kBrickElems / 64; k++) {
+            const int e = k * 64 + lane;
+            dst[e] = (T)v[k];
+            if (e < kRow * kRow * kRow) {      // the 39 elements of padding behind the 9^3 voxels stay out of the range
+                mn = v[k] < mn ? v[k] : mn;
+                mx = v[k] > mx ? v[k] : mx;
+            }
         }
-        cells[brick] = mn | (mx << 16);
-    }
-    __syncthreads();  // s_mn / s_mx are reused by the next brick
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t a = __shfl_xor(mn, o), b = __shfl_xor(mx, o);
+            mn = a < mn ? a : mn;
+            mx = b > mx ? b : mx;
+        }
+        if (lane == 0) cells[brick] = mn | (mx << 16);
     }
 }
 
