@@ -357,6 +357,30 @@ def test_count_hit_rays(ctx, oracle):
         assert ctx.count_hit_rays(200, 120) == oracle.count_hits(vp[4:8], m, 200, 120)
 
 
+def test_config2_strip_matches_the_checker(ctx, oracle):
+    # BASELINE configs[1]: 512^3 uint16 phantom at 1920x1080, half-voxel sampling (1773 samples per ray):
+    # a 48-row strip through the middle of the frame against the checker, in the fast and the skipping mode
+    n, w, h = 512, 1920, 1080
+    samples = int(math.ceil(2 * math.sqrt(3) * n)) - 1
+    vox = oracle.phantom(n, np.uint16)
+    ctx.upload_volume(vox)
+    ctx.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+    ctx.set_sampling(samples, (0, 0, 0, 0))
+    cam = (math.radians(30.0), math.radians(20.0))
+    ctx.set_camera(*cam)
+    vol, _ = oracle.normalize(vox)
+    del vox
+    lut = np.zeros((256, 4), np.float32)
+    oracle.lut_update(lut, cf.TF_GRAPHS)
+    vp, m = oracle.camera(cam[0], cam[1], w, h)
+    rows = (516, 564)
+    want = oracle.render(vol, lut, vp[4:8], m, w, h, samples, rows=rows)[rows[0]:rows[1]]
+    for mode in (1, 2):
+        ctx.set_mode(mode)
+        got = ctx.render(w, h, rect=(0, rows[0], w, rows[1]))
+        check_frame(got, want, "512^3 1080p strip mode %d" % mode)
+
+
 def test_full_size_volume_all_modes_agree(vr, torch):
     # BASELINE's headline size: 2048^3 uint16 (17 GB raw, 26 GB of bricks) generated on the device.
     # No CPU frame exists at this size; the property checked is that the fast march, the skipping
