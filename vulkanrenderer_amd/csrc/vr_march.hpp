@@ -746,18 +746,25 @@ struct Decider {
     }
     __device__ __forceinline__ bool decide(double F0, double F1, double F2, double tr, float S, int taps_left, uint32_t &rgba) const
     {
-        const float spread = S * 1.001f + (float)tr * (float)taps_left;
+        // The interval ends are formed in float (double arithmetic runs at half rate and this test is a
+        // sizeable part of the wave-per-ray march), pushed outwards by more than that arithmetic can
+        // lose (u = 2^-24): F and tr converted to float (u |F|, u tr |c|), the fused multiply-add, the
+        // term e and the two subtractions (u of their results each) -- at most 6 u (|F| + tr max|c| + e)
+        // in all; 8 u is taken.
+        const float trf = (float)tr;
+        const float spread = (S * 1.001f + trf * (float)taps_left) * 1.000001f;
         uint32_t bytes = 0xff000000u;
         bool same = true;
         const double Fc[3] = {F0, F1, F2};
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            const double e = (double)kappa[c] * (double)spread;
-            double lo = Fc[c] + tr * (double)cmin[c] - e;
-            double hi = Fc[c] + tr * (double)cmax[c] + e;
-            lo -= fabs(lo) * 1e-7 + 1e-38;      // survive the rounding of the conversion to float
-            hi += fabs(hi) * 1e-7 + 1e-38;
-            const uint32_t bl = to_unorm8((float)lo), bh = to_unorm8((float)hi);
+            const float Ff = (float)Fc[c];
+            const float e = kappa[c] * spread;
+            const float m = fabsf(Ff) + trf * fmaxf(fabsf(cmin[c]), fabsf(cmax[c])) + e;
+            const float slack = __builtin_fmaf(m, 8.0f * kUlpHalf, 1e-38f);
+            const float lo = (__builtin_fmaf(trf, cmin[c], Ff) - e) - slack;
+            const float hi = (__builtin_fmaf(trf, cmax[c], Ff) + e) + slack;
+            const uint32_t bl = to_unorm8(lo), bh = to_unorm8(hi);
             same = same && (bl == bh);
             bytes |= bl << (8 * c);
         }
