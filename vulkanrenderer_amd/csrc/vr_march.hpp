@@ -748,9 +748,10 @@ struct Decider {
     {
         // The interval ends are formed in float (double arithmetic runs at half rate and this test is a
         // sizeable part of the wave-per-ray march), pushed outwards by more than that arithmetic can
-        // lose (u = 2^-24): F and tr converted to float (u |F|, u tr |c|), the fused multiply-add, the
-        // term e and the two subtractions (u of their results each) -- at most 6 u (|F| + tr max|c| + e)
-        // in all; 8 u is taken.
+        // lose (u = 2^-24): F and tr converted to float (u |F| + u tr |c|), the product e (u e), the fused
+        // multiply-add and the two subtractions (u of their results each, which are at most
+        // m = |F| + tr max|c| + e in magnitude) -- at most 4 u m in all; 5 u m is taken.  Every unit of
+        // slack costs rays: an interval that straddles a rounding boundary sends its ray to the replay.
         const float trf = (float)tr;
         const float spread = (S * 1.001f + trf * (float)taps_left) * 1.000001f;
         uint32_t bytes = 0xff000000u;
@@ -761,7 +762,7 @@ struct Decider {
             const float Ff = (float)Fc[c];
             const float e = kappa[c] * spread;
             const float m = fabsf(Ff) + trf * fmaxf(fabsf(cmin[c]), fabsf(cmax[c])) + e;
-            const float slack = __builtin_fmaf(m, 8.0f * kUlpHalf, 1e-38f);
+            const float slack = __builtin_fmaf(m, 5.0f * kUlpHalf, 1e-38f);
             const float lo = (__builtin_fmaf(trf, cmin[c], Ff) - e) - slack;
             const float hi = (__builtin_fmaf(trf, cmax[c], Ff) + e) + slack;
             const uint32_t bl = to_unorm8(lo), bh = to_unorm8(hi);
