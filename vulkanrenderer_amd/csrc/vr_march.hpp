@@ -1409,7 +1409,10 @@ __device__ __forceinline__ void blend_under(Blend &front, const Blend &back)
     front.s = front.s + (float)front.tr * back.s;
     front.tr = front.tr * back.tr;
 }
-constexpr int kSerialFoldMax = 8;    // up to this many lanes' taps of a chunk are blended one lane after the other
+#ifndef VR_SERIAL_FOLD_MAX
+#define VR_SERIAL_FOLD_MAX 8
+#endif
+constexpr int kSerialFoldMax = VR_SERIAL_FOLD_MAX;    // up to this many lanes' taps of a chunk are blended one lane after the other
 #ifndef VR_LONG_TAPS
 #define VR_LONG_TAPS 2
 #endif
