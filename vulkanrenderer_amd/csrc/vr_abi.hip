@@ -402,7 +402,7 @@ void launch_frame_as(vr_ctx *ctx, const vr::FrameParams &fp, uint32_t *d_out, co
             (void)hipEventRecord(fb.main_done, s);
             (void)hipStreamWaitEvent(ts, fb.main_done, 0);
         }
-        hipLaunchKernelGGL((vr::k_march_long<T, STATS, SHADE>), replay_grid, dim3(256), 0, ts, vol, fp, lut, border, ctx->lut_info, d_out, fb.counters, ctx->touched, fb.queue, fb.long_queue, tiles, tiles_x);
+        hipLaunchKernelGGL((vr::k_march_long<T, STATS, SHADE>), replay_grid, dim3(256), 0, ts, vol, fp, lut, border, ctx->lut_info, d_out, fb.counters, ctx->touched, fb.queue, fb.long_queue);
         hipLaunchKernelGGL((vr::k_replay_exact<T, STATS, SHADE>), replay_grid, dim3(256), 0, ts, vol, fp, lut, border, ctx->lut_info, d_out, fb.counters, ctx->touched, fb.queue, tiles, tiles_x);
     }
 }
@@ -1262,10 +1262,10 @@ int vr_render_partial(vr_ctx *ctx, int width, int height, float *out, int out_is
     }
     if (ctx->dtype == VR_DTYPE_U8) {
         hipLaunchKernelGGL((vr::k_march_partial<uint8_t>), dim3((unsigned)tiles), dim3(64), 0, ctx->stream, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->long_queue, ctx->partial_budget, range, tiles_x);
-        hipLaunchKernelGGL((vr::k_partial_long<uint8_t>), long_grid, dim3(256), 0, ctx->stream, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->long_queue, range, tiles_x);
+        hipLaunchKernelGGL((vr::k_partial_long<uint8_t>), long_grid, dim3(256), 0, ctx->stream, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->long_queue);
     } else {
         hipLaunchKernelGGL((vr::k_march_partial<uint16_t>), dim3((unsigned)tiles), dim3(64), 0, ctx->stream, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->long_queue, ctx->partial_budget, range, tiles_x);
-        hipLaunchKernelGGL((vr::k_partial_long<uint16_t>), long_grid, dim3(256), 0, ctx->stream, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->long_queue, range, tiles_x);
+        hipLaunchKernelGGL((vr::k_partial_long<uint16_t>), long_grid, dim3(256), 0, ctx->stream, vol, fp, lut, border, ctx->lut_info, d_out, ctx->counters, ctx->long_queue);
     }
     VR_HIP(ctx, hipGetLastError());
     if (!out_is_device) {

@@ -1427,8 +1427,7 @@ constexpr int kLongTaps = VR_LONG_TAPS;   // consecutive taps per lane and round
 template <typename T, bool STATS, bool PARTIAL = false, bool SHADE = false>
 __device__ __forceinline__ bool continue_ray(const VolumeView &vol, const FrameParams &fp, const float4 *s_lut,
                                              const Decider &dec, Counters *ctr, uint32_t *touched, const LongRay &e,
-                                             uint32_t &rgba, const uint2 *__restrict__ tiles, int tiles_x,
-                                             float *__restrict__ partial_out = nullptr)
+                                             uint32_t &rgba, float *__restrict__ partial_out = nullptr)
 {
     const int lane = threadIdx.x & 63;
     // the ray and its clipped tap range as the lane march left them (identical in every lane)
@@ -1561,8 +1560,7 @@ template <typename T, bool STATS, bool SHADE>
 __global__ __launch_bounds__(256, VR_LONG_MIN_WAVES) void k_march_long(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
                                                    float4 border, const LutInfo *__restrict__ info,
                                                    uint32_t *__restrict__ out, Counters *ctr, uint32_t *touched,
-                                                   uint32_t *__restrict__ queue, const LongRay *__restrict__ long_queue,
-                                                   const uint2 *__restrict__ tiles, int tiles_x)
+                                                   uint32_t *__restrict__ queue, const LongRay *__restrict__ long_queue)
 {
     __shared__ float4 s_lut[kLutLds];
     stage_lut(s_lut, lut, border);
@@ -1573,7 +1571,7 @@ __global__ __launch_bounds__(256, VR_LONG_MIN_WAVES) void k_march_long(VolumeVie
     for (uint32_t entry = blockIdx.x * 4u + (threadIdx.x >> 6); entry < entries; entry += waves) {
         const LongRay e = long_queue[entry];
         uint32_t rgba;
-        const bool decided = continue_ray<T, STATS, false, SHADE>(vol, fp, s_lut, dec, ctr, touched, e, rgba, tiles, tiles_x);
+        const bool decided = continue_ray<T, STATS, false, SHADE>(vol, fp, s_lut, dec, ctr, touched, e, rgba);
         if (lane == 0) {
             if (decided) out[e.pixel_id] = rgba;
             else queue[atomicAdd(&ctr->replay_count, 1u)] = e.pixel_id;

@@ -90,8 +90,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_partial_long(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
                                                      float4 border, const LutInfo *__restrict__ info,
                                                      float *__restrict__ out, Counters *ctr,
-                                                     const LongRay *__restrict__ long_queue,
-                                                     const uint2 *__restrict__ tiles, int tiles_x)
+                                                     const LongRay *__restrict__ long_queue)
 {
     __shared__ float4 s_lut[kLutLds];
     stage_lut(s_lut, lut, border);
@@ -101,7 +100,7 @@ __global__ __launch_bounds__(256) void k_partial_long(VolumeView vol, FrameParam
     for (uint32_t entry = blockIdx.x * 4u + (threadIdx.x >> 6); entry < entries; entry += waves) {
         const LongRay e = long_queue[entry];
         uint32_t rgba;
-        continue_ray<T, false, true>(vol, fp, s_lut, dec, ctr, nullptr, e, rgba, tiles, tiles_x, out);
+        continue_ray<T, false, true>(vol, fp, s_lut, dec, ctr, nullptr, e, rgba, out);
     }
 }
 
