@@ -43,3 +43,19 @@ def test_camera_uniforms_rejects_degenerate_extent():
 def test_control_point_intensity(oracle):
     for y, hgt in ((0.0, 300.0), (299.0, 300.0), (17.0, 123.0)):
         assert vr.control_point_intensity(y, hgt) == oracle.control_point_intensity(y, hgt)
+
+
+def test_binding_argument_counts_match_the_header():
+    """Every prototype of the header has as many parameters as the ctypes binding declares for it."""
+    text = open(os.path.join(cf.ROOT, "include", "vr_abi.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    L = vr.lib()
+    checked = 0
+    for name, params in re.findall(r"\b(vr_[a-z_0-9]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        params = params.strip()
+        count = 0 if params in ("", "void") else len(params.split(","))
+        argtypes = getattr(L, name).argtypes
+        assert argtypes is not None, "no argtypes for %s" % name
+        assert len(argtypes) == count, (name, len(argtypes), count)
+        checked += 1
+    assert checked == len(vr.ABI_SYMBOLS)
