@@ -99,10 +99,6 @@ def main():
     # Rehearsal switches (not used by a normal run): several ranks on one GPU, exchanging over gloo
     # through host memory, to exercise the multi-rank control flow where only one GPU is at hand.
     backend = os.environ.get("VR_BENCH_BACKEND", "nccl")
-    if world == 1:
-        # the only process on its GPU: the kernels that finish a frame may run at high stream priority
-        # (with several ranks the collective's own kernels share the GPU's queues, so they keep the default)
-        os.environ.setdefault("VR_TAIL_PRIORITY", "1")
     if os.environ.get("VR_BENCH_ONE_DEVICE"):
         local_rank = 0
     torch.cuda.set_device(local_rank)
