@@ -18,6 +18,7 @@ ap.add_argument("--height", type=int, default=2160)
 ap.add_argument("--frames", type=int, default=4)
 ap.add_argument("--mode", type=int, default=1)
 ap.add_argument("--parts", type=int, default=1, help="render only sort-first part 0 of this many")
+ap.add_argument("--shading", action="store_true", help="gradient lighting on")
 a = ap.parse_args()
 n = a.volume
 ctx = vr.VolumeRenderer(0)
@@ -30,6 +31,8 @@ del raw
 ctx.update_transfer_function(bench.TF_GRAPHS, reset_state=True)
 ctx.set_sampling(bench.samples_for(n))
 ctx.set_mode(a.mode)
+if a.shading:
+    ctx.set_shading(True)
 out = torch.empty(a.width * a.height * 4, dtype=torch.uint8, device="cuda")
 torch.cuda.synchronize()
 for i in range(a.frames):
