@@ -224,7 +224,8 @@ def main():
         achieved = agg["algorithmic_bytes"] / kern_s / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        # the counters were collected on whole-frame launches: no figure for a rank's share of the bands
+        if world == 1 and os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get("%d_%dx%d_%s%s" % (n, w, h, args.mode, "_shaded" if args.shading else ""))
             except Exception:
