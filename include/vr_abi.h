@@ -60,6 +60,12 @@ typedef struct vr_stats {
     float kernel_ms;            /* device time of the frame's kernels (hipEvent) */
     uint32_t pad_;
     uint64_t long_rays;         /* rays the lane-per-ray march handed to the wave-per-ray march */
+    /* fast mode, where the frame's taps were fetched: */
+    uint64_t long_samples;      /* taps fetched by the wave-per-ray continuation of handed-over rays */
+    uint64_t replay_samples;    /* taps fetched by the reference-order replay */
+    uint64_t main_bricks;       /* distinct bricks the lane-per-ray march alone touched */
+    uint32_t rays_by_lane_taps[24]; /* hit rays by floor(log2(taps the lane-per-ray march fetched for them + 1)) */
+    uint32_t rays_by_wave_taps[24]; /* handed-over rays by floor(log2(taps the wave-per-ray march fetched + 1)) */
 } vr_stats;
 
 /* Context life cycle.  Stands in for initComputePipeline / postRenderLoop,

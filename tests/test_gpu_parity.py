@@ -167,6 +167,47 @@ def test_slice_loader_errors(ctx, vr, tmp_path):
         ctx.load_volume_data(str(tmp_path / "missing"))
     with pytest.raises(vr.VrError):
         ctx.load_volume_data(str(tmp_path))             # empty directory (main.cpp:158)
+    # std::stoi on the key of a name (main.cpp:123-128) throws when it holds no number
+    good = np.arange(16, dtype=">u2")
+    for bad in (".hidden", "slice.", "slice.abc"):
+        d = tmp_path / ("case_" + bad.strip(".").replace(".", "_"))
+        d.mkdir()
+        good.tofile(d / "CThead.1")
+        good.tofile(d / bad)
+        with pytest.raises(vr.VrError, match="slice number"):
+            ctx.load_volume_data(str(d))
+    # ... and takes the leading digits when something follows them ("2x" sorts as 2)
+    d = tmp_path / "mixed"
+    d.mkdir()
+    good.tofile(d / "a.1")
+    (np.arange(16, 32).astype(">u2")).tofile(d / "a.2x")
+    ctx.load_volume_data(str(d))
+    info = ctx.volume_info()
+    assert (info["nx"], info["ny"], info["nz"]) == (4, 4, 2) and info["max_value"] == 31.0
+
+
+def test_failed_upload_leaves_no_volume(vr, oracle, monkeypatch):
+    """An allocation that fails in the middle of an upload must leave the context without a volume
+    (render answers with a state error), not with a half-built one."""
+    vox = oracle.phantom(24, np.uint8)
+    for nth in range(1, 11):          # bricks, cells, touched, four pyramid levels, micro, skip, occ_list
+        monkeypatch.setenv("VR_TEST_FAIL_ALLOC", str(nth))
+        with vr.VolumeRenderer(0) as c:
+            monkeypatch.delenv("VR_TEST_FAIL_ALLOC")
+            c.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+            with pytest.raises(vr.VrError, match="volume upload"):
+                c.upload_volume(vox)
+            for mode in (0, 1, 2):
+                c.set_mode(mode)
+                with pytest.raises(vr.VrError, match="no volume"):
+                    c.render(32, 32)
+            with pytest.raises(vr.VrError):
+                c.volume_info()
+            # the hook has fired; the next upload goes through and renders
+            c.upload_volume(vox)
+            c.set_mode(1)
+            c.set_sampling(40)
+            assert c.render(32, 32)[..., :3].any()
 
 
 # ---- frames ------------------------------------------------------------------------------------
@@ -450,6 +491,9 @@ def test_tune_keeps_the_frame(ctx, oracle):
     assert np.array_equal(ctx.render(160, 120), ref)
     assert ctx.tune(160, 120, 1, 3) in (64, 80, 96, 112, 128)
     assert np.array_equal(ctx.render(160, 120), ref)
+    # a part that owns no band (more parts than bands) has nothing to measure: the budget stays
+    kept = ctx.tune(160, 120, 1, 3)
+    assert ctx.tune(160, 16, 5, 8) == kept
 
 
 def test_assemble_gathered_bands(ctx, oracle, torch):
@@ -591,6 +635,12 @@ def test_shading_arguments(vr, ctx, oracle):
     zero = ctx.render(40, 40)
     ctx.set_shading(False)
     assert np.array_equal(zero, ctx.render(40, 40))
+    # the partial march (sort-last step 1) has no lighting: a whole-volume context with lighting on refuses it
+    ctx.set_shading(True)
+    with pytest.raises(vr.VrError, match="lighting"):
+        ctx.render_partial(40, 40)
+    ctx.set_shading(False)
+    assert ctx.render_partial(40, 40).shape == (1600, 5)
     # a context holding a box of the volume refuses the lighting, and the other way round
     from vulkanrenderer_amd import sortlast
     vox = oracle.phantom(32, np.uint8)

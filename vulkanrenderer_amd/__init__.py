@@ -42,10 +42,11 @@ class Stats(C.Structure):
                 ("samples_evaluated", C.c_uint64), ("cells_read", C.c_uint64),
                 ("bricks_touched", C.c_uint64), ("replay_rays", C.c_uint64),
                 ("algorithmic_bytes", C.c_uint64), ("kernel_ms", C.c_float), ("pad_", C.c_uint32),
-                ("long_rays", C.c_uint64)]
+                ("long_rays", C.c_uint64), ("long_samples", C.c_uint64), ("replay_samples", C.c_uint64),
+                ("main_bricks", C.c_uint64), ("rays_by_lane_taps", C.c_uint32 * 24), ("rays_by_wave_taps", C.c_uint32 * 24)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        return {k: (list(getattr(self, k)) if k.startswith("rays_by_") else getattr(self, k)) for k, _ in self._fields_}
 
 
 class VrError(RuntimeError):

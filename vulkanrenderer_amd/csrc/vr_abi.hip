@@ -5,6 +5,8 @@
 #include "../../include/vr_abi.h"
 
 #include <algorithm>
+#include <cerrno>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstddef>
@@ -42,7 +44,7 @@ struct vr_ctx {
     uint32_t *occ_list = nullptr;         // indices of the occupied bricks, for the per-tile depth ranges
     uint32_t *d_occ_count = nullptr;
     uint32_t occ_count = 0;
-    uint2 *tiles = nullptr;               // per 32x32 pixel tile: depth range of the occupied bricks (fast mode)
+    uint2 *tiles = nullptr;               // per 8x8 pixel tile: depth range of the occupied bricks (fast mode)
     size_t tiles_cap = 0;
     bool tile_clip = true;
     bool occupancy_dirty = true;
@@ -102,6 +104,9 @@ struct vr_ctx {
     size_t alt_queue_cap = 0;
     uint2 *tiles_alt = nullptr;
     size_t alt_tiles_cap = 0;
+    // test hook (VR_TEST_FAIL_ALLOC=n at vr_create): the n-th device allocation of a volume upload
+    // fails, so that the error path of the upload can be exercised without exhausting the GPU
+    int fail_alloc_in = 0;
 };
 
 namespace {
@@ -118,6 +123,17 @@ int fail(vr_ctx *ctx, int code, const std::string &msg)
         if (e_ != hipSuccess)                                                                          \
             return fail((ctx), VR_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));         \
     } while (0)
+
+// Device allocation of a volume upload; honours the context's test hook.
+template <typename P>
+hipError_t volume_alloc(vr_ctx *ctx, P **ptr, size_t bytes)
+{
+    if (ctx->fail_alloc_in > 0 && --ctx->fail_alloc_in == 0) {
+        *ptr = nullptr;
+        return hipErrorOutOfMemory;
+    }
+    return hipMalloc(ptr, bytes);
+}
 
 int bind(vr_ctx *ctx)
 {
@@ -251,6 +267,11 @@ int ingest_device(vr_ctx *ctx, T *d_raw, int nx, int ny, int nz, float max_value
     if (mx > 65535.0f) return fail(ctx, VR_ERR_ARG, "max_value above 65535");
 
     if (sub && ctx->shading) return fail(ctx, VR_ERR_STATE, "shading is on: a sub-volume's apron does not hold the neighbours the gradient reads");
+    const size_t brick_count = (size_t)(hi[0] - lo[0]) * (size_t)(hi[1] - lo[1]) * (size_t)(hi[2] - lo[2]);
+    if (brick_count >= (1ull << 31)) return fail(ctx, VR_ERR_ARG, "volume too large");
+    // From here on the old volume is gone.  The upload is all or nothing: when any step below fails
+    // the context is left without a volume (vr_render then answers VR_ERR_STATE), never with a
+    // half-built one whose tables are null.
     release_volume(ctx);
     ctx->nx = nx; ctx->ny = ny; ctx->nz = nz;
     ctx->nbx = hi[0] - lo[0];
@@ -258,32 +279,38 @@ int ingest_device(vr_ctx *ctx, T *d_raw, int nx, int ny, int nz, float max_value
     ctx->nbz = hi[2] - lo[2];
     ctx->sub = sub;
     for (int k = 0; k < 3; k++) ctx->brick_lo[k] = lo[k];
-    ctx->brick_count = (size_t)ctx->nbx * ctx->nby * ctx->nbz;
-    if (ctx->brick_count >= (1ull << 31)) return fail(ctx, VR_ERR_ARG, "volume too large");
+    ctx->brick_count = brick_count;
     ctx->dtype = (int)sizeof(T);
     ctx->max_value = mx;
     // v / max == fma(v, inv_hi, v * inv_lo) bit for bit for all integers 0 <= v <= max <= 65535
     ctx->inv_hi = 1.0f / mx;
     ctx->inv_lo = (float)(1.0 / (double)mx - (double)ctx->inv_hi);
-    VR_HIP(ctx, hipMalloc(&ctx->bricks, ctx->brick_count * vr::kBrickElems * sizeof(T)));
-    VR_HIP(ctx, hipMalloc(&ctx->cells, ctx->brick_count * sizeof(uint32_t)));
-    VR_HIP(ctx, hipMalloc(&ctx->touched, ((ctx->brick_count + 31) / 32) * sizeof(uint32_t)));
+    hipError_t err = volume_alloc(ctx, &ctx->bricks, brick_count * vr::kBrickElems * sizeof(T));
+    if (err == hipSuccess) err = volume_alloc(ctx, &ctx->cells, brick_count * sizeof(uint32_t));
+    if (err == hipSuccess) err = volume_alloc(ctx, &ctx->touched, ((brick_count + 31) / 32) * sizeof(uint32_t));
     for (int l = 0; l < vr::kLevels; l++) {
         ctx->lx[l] = l == 0 ? ctx->nbx : (ctx->lx[l - 1] + 3) / 4;
         ctx->ly[l] = l == 0 ? ctx->nby : (ctx->ly[l - 1] + 3) / 4;
         ctx->lz[l] = l == 0 ? ctx->nbz : (ctx->lz[l - 1] + 3) / 4;
         const size_t cubes = (size_t)ctx->lx[l] * ctx->ly[l] * ctx->lz[l];
-        VR_HIP(ctx, hipMalloc(&ctx->empty[l], ((cubes + 31) / 32) * sizeof(uint32_t)));
+        if (err == hipSuccess) err = volume_alloc(ctx, &ctx->empty[l], ((cubes + 31) / 32) * sizeof(uint32_t));
     }
-    VR_HIP(ctx, hipMalloc(&ctx->micro, ctx->brick_count * sizeof(unsigned long long)));
-    VR_HIP(ctx, hipMalloc(&ctx->skip, ((ctx->brick_count + 15) / 16) * sizeof(uint32_t)));
-    VR_HIP(ctx, hipMalloc(&ctx->occ_list, ctx->brick_count * sizeof(uint32_t)));
+    if (err == hipSuccess) err = volume_alloc(ctx, &ctx->micro, brick_count * sizeof(unsigned long long));
+    if (err == hipSuccess) err = volume_alloc(ctx, &ctx->skip, ((brick_count + 15) / 16) * sizeof(uint32_t));
+    if (err == hipSuccess) err = volume_alloc(ctx, &ctx->occ_list, brick_count * sizeof(uint32_t));
+    if (err == hipSuccess) {
+        const unsigned brick_blocks = (unsigned)std::min<size_t>((brick_count + 3) / 4, 1u << 20);   // four waves, a brick each
+        hipLaunchKernelGGL((vr::k_build_bricks<T>), dim3(brick_blocks), dim3(256), 0, ctx->stream, (const T *)d_raw,
+                           (T *)ctx->bricks, ctx->cells, nx, ny, nz, ctx->nbx, ctx->nby, (uint32_t)brick_count, src);
+        err = hipGetLastError();
+    }
+    if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
+    if (err != hipSuccess) {
+        (void)hipGetLastError();   // an allocation failure is not sticky; clear it for the calls that follow
+        release_volume(ctx);
+        return fail(ctx, VR_ERR_HIP, std::string("volume upload: ") + hipGetErrorString(err));
+    }
     ctx->occupancy_dirty = true;
-    const unsigned brick_blocks = (unsigned)std::min<size_t>((ctx->brick_count + 3) / 4, 1u << 20);   // four waves, a brick each
-    hipLaunchKernelGGL((vr::k_build_bricks<T>), dim3(brick_blocks), dim3(256), 0, ctx->stream, (const T *)d_raw,
-                       (T *)ctx->bricks, ctx->cells, nx, ny, nz, ctx->nbx, ctx->nby, (uint32_t)ctx->brick_count, src);
-    VR_HIP(ctx, hipGetLastError());
-    VR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return VR_OK;
 }
 
@@ -310,9 +337,9 @@ int refresh_occupancy(vr_ctx *ctx)
         hipLaunchKernelGGL(vr::k_classify_up, dim3((cubes + 255) / 256), dim3(256), 0, ctx->stream, ctx->empty[l - 1], ctx->lx[l - 1],
                            ctx->ly[l - 1], ctx->lz[l - 1], ctx->lx[l], ctx->ly[l], ctx->lz[l], ctx->empty[l]);
     }
-    const int occ_init[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, -1, -1, -1};
-    VR_HIP(ctx, hipMemcpyAsync(ctx->occ, occ_init, sizeof occ_init, hipMemcpyHostToDevice, ctx->stream));
-    VR_HIP(ctx, hipStreamSynchronize(ctx->stream));  // occ_init lives on this stack frame
+    // empty box: lo = INT_MAX, hi = -1
+    VR_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)ctx->occ, 0x7fffffff, 3, ctx->stream));
+    VR_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctx->occ + 3), -1, 3, ctx->stream));
     hipLaunchKernelGGL(vr::k_occupied_bounds, dim3(1024), dim3(256), 0, ctx->stream, ctx->empty[0], ctx->lx[0], ctx->ly[0], ctx->lz[0],
                        ctx->occ);
     const unsigned skip_words = (bricks + 15) / 16;
@@ -397,6 +424,8 @@ void launch_frame_as(vr_ctx *ctx, const vr::FrameParams &fp, uint32_t *d_out, co
         const dim3 replay_grid((unsigned)ctx->tail_blocks);  // 4 waves each, one ray per wave and pass
         hipLaunchKernelGGL((vr::k_march_fast<T, STATS, SHADE>), grid, block, 0, s, vol, fp, lut, border, ctx->lut_info, d_out, fb.counters, ctx->touched, fb.queue, fb.long_queue, ctx->lane_budget, tiles, tiles_x);
         (void)hipEventRecord(ctx->ring_b[slot], s);
+        if (STATS)
+            hipLaunchKernelGGL(vr::k_count_bits, dim3(1024), dim3(256), 0, s, ctx->touched, (ctx->brick_count + 31) / 32, &fb.counters->main_bricks);
         hipStream_t ts = fb.tail;
         if (fb.main_done) {
             (void)hipEventRecord(fb.main_done, s);
@@ -444,6 +473,7 @@ int vr_create(int device, vr_ctx **out)
         vr_destroy(ctx);
         return VR_ERR_HIP;
     }
+    if (const char *e = std::getenv("VR_TEST_FAIL_ALLOC")) ctx->fail_alloc_in = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("VR_TILE_CLIP")) ctx->tile_clip = std::atoi(e) != 0;
     if (const char *e = std::getenv("VR_LANE_BUDGET")) ctx->lane_budget = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("VR_PARTIAL_BUDGET")) ctx->partial_budget = std::max(1, std::atoi(e));
@@ -591,7 +621,14 @@ int vr_load_volume_slices(vr_ctx *ctx, const char *directory)
         // main.cpp:123-128: the integer after the extension dot, or the whole file name
         const fs::path &p = it->path();
         std::string key = p.has_extension() ? p.extension().string().substr(1) : p.filename().string();
-        files.emplace_back(std::atoi(key.c_str()), p);
+        // std::stoi there: leading blanks, a sign and digits, anything after them ignored; a key without
+        // digits (a hidden file, a name ending in a dot) or beyond int throws and ends the application
+        errno = 0;
+        char *rest = nullptr;
+        const long number = std::strtol(key.c_str(), &rest, 10);
+        if (rest == key.c_str() || errno == ERANGE || number < INT_MIN || number > INT_MAX)
+            return fail(ctx, VR_ERR_IO, "slice file name without a slice number: " + p.string());
+        files.emplace_back((int)number, p);
     }
     if (ec) return fail(ctx, VR_ERR_IO, std::string("cannot list ") + directory + ": " + ec.message());
     if (files.empty()) return fail(ctx, VR_ERR_IO, std::string("Unavailable volume data files for loading at ") + directory);  // main.cpp:158
@@ -984,6 +1021,13 @@ static int render_impl(vr_ctx *ctx, int width, int height, int x0, int y0, int x
         stats->bricks_touched = touched;
         stats->replay_rays = c.replay_rays;
         stats->long_rays = c.long_count;
+        stats->long_samples = c.long_samples;
+        stats->replay_samples = c.replay_samples;
+        stats->main_bricks = c.main_bricks;
+        for (int k = 0; k < 24; k++) {
+            stats->rays_by_lane_taps[k] = c.hist_lane[k];
+            stats->rays_by_wave_taps[k] = c.hist_long[k];
+        }
         const uint64_t brick_bytes = (uint64_t)vr::kBrick * vr::kBrick * vr::kBrick * (uint64_t)ctx->dtype;
         // bricks fetched + (fast/skip modes) the occupancy pyramid's bits + LUT + frame
         uint64_t occupancy = 0;
@@ -1034,8 +1078,13 @@ int vr_tune(vr_ctx *ctx, int width, int height, int part, int parts, int *chosen
     if (!ctx->bricks) return fail(ctx, VR_ERR_STATE, "no volume uploaded");
     if (ctx->sub) return fail(ctx, VR_ERR_STATE, "the context holds a sub-volume");
     if (parts < 1 || part < 0 || part >= parts) return fail(ctx, VR_ERR_ARG, "bad part");
+    if (width < 2 || height < 2 || width > 65536 || height > 65536) return fail(ctx, VR_ERR_ARG, "image size out of range");
+    if (rows_of_part(height, part, parts) == 0) {   // more parts than bands: this part renders nothing, nothing to measure
+        if (chosen_budget) *chosen_budget = ctx->lane_budget;
+        return VR_OK;
+    }
     if (int rc = bind(ctx)) return rc;
-    const size_t pixels = (size_t)width * (size_t)std::max(1, rows_of_part(height, part, parts));
+    const size_t pixels = (size_t)width * (size_t)rows_of_part(height, part, parts);
     uint8_t *scratch = nullptr;
     VR_HIP(ctx, hipMalloc(&scratch, pixels * 4));
     const int mode = ctx->mode, depth = ctx->pipeline_depth, before = ctx->lane_budget;
@@ -1209,6 +1258,7 @@ int vr_render_partial(vr_ctx *ctx, int width, int height, float *out, int out_is
 {
     if (!ctx || !out) return fail(ctx, VR_ERR_ARG, "null argument");
     if (!ctx->bricks) return fail(ctx, VR_ERR_STATE, "no volume uploaded");
+    if (ctx->shading) return fail(ctx, VR_ERR_STATE, "shading is on: the partial march has no lighting");
     if (int rc = bind(ctx)) return rc;
     vr::FrameParams fp;
     if (int rc = frame_params(ctx, width, height, fp)) return rc;

@@ -73,6 +73,12 @@ struct Counters {
     unsigned int long_count;    // fast mode: rays handed from the lane march to the wave march
     unsigned int clip_off;      // fast mode: the per-tile depth ranges could not be built for this camera
     unsigned int pad0_;
+    // counting builds only: where the taps of a fast frame are fetched
+    unsigned long long long_samples;     // by the wave-per-ray continuation
+    unsigned long long replay_samples;   // by the reference-order replay
+    unsigned long long main_bricks;      // bricks touched by the lane march alone
+    unsigned int hist_lane[24];          // rays by floor(log2(taps the lane march fetched for them + 1))
+    unsigned int hist_long[24];          // handed-over rays by floor(log2(taps the wave march fetched + 1))
     // everything above is cleared at the start of a frame; what follows persists
     unsigned int lut_error;
     unsigned int pad_;

@@ -275,6 +275,12 @@ __device__ __forceinline__ RayModel ray_model(const Ray &r, const VolumeView &v,
     m.iz = dz != 0.0f ? __builtin_amdgcn_rcpf(dz) : 0.0f;
     const float big = fmaxf(v.fx, fmaxf(v.fy, v.fz));
     m.margin = fmaxf(0.02f, big * 1e-5f);
+    if (v.occ[0] > v.occ[3]) {
+        // no brick is occupied (a fully transparent table): no tap in front of the back-most one matters
+        m.t_first = 0;
+        m.t_stop = 0x7fffffff;
+        return m;
+    }
     // clip the tap range against the box of occupied bricks: G(t) = a + t*b inside [L, U] per axis
     float t_lo = 0.0f, t_hi = 3e9f;
     const float a[3] = {m.ax, m.ay, m.az}, b[3] = {m.bx, m.by, m.bz}, inv[3] = {dir * m.ix, dir * m.iy, dir * m.iz};
@@ -328,14 +334,15 @@ __global__ __launch_bounds__(256) void k_occupied_bounds(const uint32_t *__restr
     }
 }
 
-// ---- depth range of the occupied bricks per 32x32 pixel tile ----------------------------------------
+// ---- depth range of the occupied bricks per pixel tile (8x8 pixels, 1 << kRangeShift) ---------------
 // Before a frame every occupied brick is projected into the image and widens, for each tile its
 // projection touches, the tile's range [near, far] of distances from the eye.  A ray then only looks
 // at the taps inside its tile's range: rays of tiles no brick touches are finished at once, the others
 // start a few voxels in front of the first occupied brick instead of at the volume's face.
 // Stored per tile as two numbers that only grow, so that a cleared buffer means "nothing":
-// x = 0x7f800000 - bits(near), y = bits(far).  32 pixels: a brick of a 2048^3 volume projects to about
-// that much of a 4K frame, so it touches a handful of tiles (the cost of this pass is its atomics).
+// x = 0x7f800000 - bits(near), y = bits(far).  A tile is the 8x8 pixels one wave of the lane march owns, so
+// the range is as tight as the wave can use; a brick of a 2048^3 volume projects to about 3x3 pixels of a
+// 4K frame and touches one to four tiles (the cost of this pass is its atomics, merged per block in LDS).
 #ifndef VR_RANGE_SHIFT
 #define VR_RANGE_SHIFT 3
 #endif
@@ -937,6 +944,7 @@ __device__ __forceinline__ void replay_ray(const VolumeView &vol, const FramePar
     if (STATS) {
         if (lane == 0) atomicAdd(&ctr->replay_rays, 1ull);
         atomicAdd(&ctr->samples_evaluated, evaluated);
+        atomicAdd(&ctr->replay_samples, evaluated);
     }
 }
 
@@ -1342,6 +1350,7 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
         atomicAdd(&ctr->rays_hit, r.hit ? 1ull : 0ull);
         atomicAdd(&ctr->samples_evaluated, evaluated);
         atomicAdd(&ctr->cells_read, lookups);
+        if (r.hit && !PARTIAL) atomicAdd(&ctr->hist_lane[63 - __builtin_clzll(evaluated + 1ull)], 1u);
     }
 #ifdef VR_DIAG
     // diagnostic build only: wave start/end wall clock (100 MHz) and placement, one record per wave
@@ -1547,7 +1556,12 @@ __device__ __forceinline__ bool continue_ray(const VolumeView &vol, const FrameP
         F2 = __builtin_fma(Tr, (double)tf.z, F2);
         decided = dec.ok && dec.decide(F0, F1, F2, 0.0, S, 0, rgba);
     }
-    if (STATS) atomicAdd(&ctr->samples_evaluated, evaluated);
+    if (STATS) {
+        atomicAdd(&ctr->samples_evaluated, evaluated);
+        atomicAdd(&ctr->long_samples, evaluated);
+        for (int o = 32; o > 0; o >>= 1) evaluated += __shfl_xor(evaluated, o);
+        if (lane == 0) atomicAdd(&ctr->hist_long[63 - __builtin_clzll(evaluated + 1ull)], 1u);
+    }
     return decided;
 }
 
@@ -1594,6 +1608,15 @@ __global__ __launch_bounds__(256) void k_replay_exact(VolumeView vol, FrameParam
     const uint32_t entries = ctr->replay_count;
     for (uint32_t entry = blockIdx.x * 4u + (threadIdx.x >> 6); entry < entries; entry += waves)
         replay_ray<T, STATS, false, SHADE>(vol, fp, s_lut, dec, out, ctr, touched, queue[entry], tiles, tiles_x);
+}
+
+// Number of set bits of a bit map, added to *total (counting builds: bricks touched so far).
+__global__ __launch_bounds__(256) void k_count_bits(const uint32_t *__restrict__ bits, size_t words, unsigned long long *total)
+{
+    unsigned long long n = 0;
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < words; i += (size_t)gridDim.x * 256u) n += (unsigned long long)__popc(bits[i]);
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+    if ((threadIdx.x & 63) == 0 && n) atomicAdd(total, n);
 }
 
 // Rays of the rectangle that hit the box (the reference marches samples + 2 taps on each).

@@ -51,6 +51,10 @@ class SortFirstFrame:
                 self.recv = torch.zeros((world, self.padded_rows, width, 4), dtype=torch.uint8, device=self.device)
                 self.perm = torch.from_numpy(band_permutation(height, world, self.padded_rows)).to(self.device)
             self.frame = torch.zeros((height, width, 4), dtype=torch.uint8, device=self.device)
+        # the fills above ran on torch's current stream, the renderer writes the buffers on its own
+        # (non-blocking) stream: nothing else orders the two
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
 
     @property
     def local(self):

@@ -165,6 +165,10 @@ class SortLastFrame:
         self.undecided_count = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.frame = torch.zeros((self.padded, 4), dtype=torch.uint8, device=self.device) if rank == 0 else None
         self.remarched = 0      # pixels the last frame sent through step 4
+        # the fills above ran on torch's current stream, the kernels that write these buffers run on the
+        # context's own (non-blocking) stream: nothing else orders the two
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
 
     # -- collectives, optionally staged through the host ------------------------------------------
     def _host(self, t):
