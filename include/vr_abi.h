@@ -151,6 +151,24 @@ int vr_render(vr_ctx *ctx, int width, int height, uint8_t *out, int out_is_devic
 int vr_render_rect(vr_ctx *ctx, int width, int height, int x0, int y0, int x1, int y1,
                    uint8_t *out, int out_is_device, vr_stats *stats);
 
+/* One frame without any allocation.  No counterpart in the reference (whose frame loop owns all its
+ * Vulkan objects up front, main.cpp:203-573, and never runs under a capture); it is for callers that
+ * cannot allocate device memory: code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  Same frame as vr_render(ctx, width, height, d_out, 1, NULL) with VR_MODE_FAST, whatever mode
+ * is set, never pipelined; d_out is a device pointer, the call is asynchronous on the context's stream.
+ * The scratch a fast frame needs (counters, per-tile depth ranges, the queues of handed-over and of
+ * undecided rays) comes from a static device array inside the library (about 70 MB, held by every GPU the
+ * library runs on until the process ends) instead of buffers allocated on demand, so the frame is limited
+ * to VR_STATIC_MAX_PIXELS pixels and 2 * VR_STATIC_MAX_PIXELS / 64 tiles of 8x8 pixels (VR_ERR_ARG
+ * beyond).  The call allocates and frees nothing, on the device or through any library; the volume and
+ * the transfer function must have been set before (their calls allocate).  The first frame after a change of
+ * table, border colour, shading or volume rebuilds the occupancy tables and waits for the stream once.  All
+ * contexts on one GPU share that GPU's array: calls that overlap on one GPU, from two contexts or
+ * two streams, race. */
+#define VR_STATIC_MAX_PIXELS (1280 * 720) /* the reference's window, main.cpp:30 */
+int vr_render_static(vr_ctx *ctx, int width, int height, uint8_t *d_out);
+int vr_static_max_pixels(void);
+
 /* Two frames in flight (no counterpart in the reference, which waits on a fence every frame,
  * Source/VulkanApplication.cpp:560-562).  With frames_in_flight == 2, VR_MODE_FAST frames rendered
  * into device memory without a stats pointer are pipelined: the kernels that finish a frame (the few

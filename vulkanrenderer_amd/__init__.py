@@ -28,7 +28,7 @@ ABI_SYMBOLS = (
     "vr_phantom_generate_device", "vr_phantom_generate_box_device",
     "vr_brick_grid", "vr_subvolume_voxels", "vr_upload_subvolume_device", "vr_render_partial",
     "vr_composite_pair", "vr_composite_ordered", "vr_decide_partials", "vr_chain_stage",
-    "vr_store_chain",
+    "vr_store_chain", "vr_render_static", "vr_static_max_pixels",
 )
 PARTIAL_FLOATS = 5   # floats per pixel of a sort-last partial result: F0, F1, F2, Tr, S
 
@@ -100,6 +100,8 @@ def lib():
     L.vr_render.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, C.POINTER(Stats)]
     L.vr_render_rect.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.POINTER(Stats)]
     L.vr_render_bands.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.POINTER(Stats)]
+    L.vr_render_static.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.vr_static_max_pixels.argtypes = []
     L.vr_set_pipeline.argtypes = [vp, C.c_int]
     L.vr_wait_frame.argtypes = [vp, vp]
     L.vr_band_rows.argtypes = [C.c_int, C.c_int, C.c_int]
@@ -175,6 +177,10 @@ def subvolume_voxels(nx, ny, nz, brick_lo, brick_hi):
     if lib().vr_subvolume_voxels(nx, ny, nz, _i3(brick_lo), _i3(brick_hi), lo, hi) != 0:
         raise VrError("vr_subvolume_voxels: bad arguments")
     return tuple(lo), tuple(hi)
+
+
+def static_max_pixels():
+    return int(lib().vr_static_max_pixels())
 
 
 def control_point_intensity(y, child_height):
@@ -367,6 +373,11 @@ class VolumeRenderer:
         self._check(lib().vr_render_rect(self._h, width, height, x0, y0, x1, y1, ptr, 1,
                                          C.byref(st) if stats else None))
         return st.as_dict() if stats else None
+
+    def render_static(self, width, height, ptr):
+        """vr_render_static: a fast frame into device memory at `ptr` that allocates nothing (scratch from the
+        library's static device array; frames up to static_max_pixels())."""
+        self._check(lib().vr_render_static(self._h, width, height, ptr))
 
     # --- sort-last: one box of the volume's brick grid per context (no reference counterpart) ---
     def phantom_generate_box_device(self, ptr, dtype_bytes, n, lo, hi, seed=0x5EED1234):

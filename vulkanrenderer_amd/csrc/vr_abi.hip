@@ -109,6 +109,28 @@ struct vr_ctx {
     int fail_alloc_in = 0;
 };
 
+// ---- scratch of the entry point that allocates nothing (vr_render_static) ---------------------------
+// What a fast frame needs beyond its input and output: the frame's counters, the per-tile depth
+// ranges, the queue of undecided pixels and the queue of handed-over rays.  vr_render takes them from
+// buffers the context allocates on demand; vr_render_static takes them from this array, which the
+// code object brings along: every GPU the library runs on holds one copy of it until the process ends.
+// In host code the array's name is only a handle for hipGetSymbolAddress; the device address it yields
+// (one per GPU) is what kernels and hipMemsetAsync get.
+namespace static_scratch {
+constexpr size_t kMaxPixels = (size_t)VR_STATIC_MAX_PIXELS;
+constexpr size_t kMaxTiles = 2 * kMaxPixels / 64;           // 8x8-pixel tiles; ragged image edges need more than pixels / 64
+constexpr size_t align_up(size_t n) { return (n + 255) & ~(size_t)255; }
+constexpr size_t kCountersAt = 0;
+constexpr size_t kTilesAt = kCountersAt + align_up(sizeof(vr::Counters));
+constexpr size_t kQueueAt = kTilesAt + align_up(kMaxTiles * sizeof(uint2));
+constexpr size_t kLongAt = kQueueAt + align_up(kMaxPixels * sizeof(uint32_t));
+constexpr size_t kBytes = kLongAt + align_up(kMaxPixels * sizeof(vr::LongRay));
+constexpr int kMaxDevices = 64;
+}  // namespace static_scratch
+static __device__ __align__(256) unsigned char scratch[static_scratch::kBytes];
+// device address of `scratch` on each GPU, looked up once per GPU by vr_create with that GPU current
+static unsigned char *g_scratch_ptr[static_scratch::kMaxDevices] = {nullptr};
+
 namespace {
 
 int fail(vr_ctx *ctx, int code, const std::string &msg)
@@ -479,6 +501,15 @@ int vr_create(int device, vr_ctx **out)
     if (const char *e = std::getenv("VR_PARTIAL_BUDGET")) ctx->partial_budget = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("VR_TAIL_BLOCKS")) ctx->tail_blocks = std::max(64, std::min(65536, std::atoi(e)));
     if (const char *e = std::getenv("VR_WAVES_PER_BLOCK")) ctx->waves_per_block = std::max(1, std::min(4, std::atoi(e)));
+    if (device < static_scratch::kMaxDevices && !g_scratch_ptr[device]) {
+        // this GPU's copy of the static scratch array (hipSetDevice(device) above made the GPU current)
+        unsigned char *ptr = nullptr;
+        if (hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)) != hipSuccess || !ptr) {
+            vr_destroy(ctx);
+            return VR_ERR_HIP;
+        }
+        g_scratch_ptr[device] = ptr;
+    }
     ctx->ring_a.resize(vr_ctx::kRing, nullptr);
     ctx->ring_b.resize(vr_ctx::kRing, nullptr);
     for (int i = 0; i < vr_ctx::kRing; i++)
@@ -882,8 +913,10 @@ int vr_set_mode(vr_ctx *ctx, int mode)
     return VR_OK;
 }
 
+// use_static: the frame's scratch comes from the static array instead of the context's buffers, and
+// nothing is allocated or freed (fast mode, device output, no counters).
 static int render_impl(vr_ctx *ctx, int width, int height, int x0, int y0, int x1, int y1, int part, int parts, uint8_t *out,
-                       int out_is_device, vr_stats *stats)
+                       int out_is_device, vr_stats *stats, bool use_static = false)
 {
     if (!ctx || !out) return fail(ctx, VR_ERR_ARG, "null argument");
     if (parts < 1 || part < 0 || part >= parts) return fail(ctx, VR_ERR_ARG, "bad sort-first part");
@@ -922,7 +955,17 @@ static int render_impl(vr_ctx *ctx, int width, int height, int x0, int y0, int x
     }
     const bool want_stats = stats != nullptr;
     const bool fast = ctx->mode == VR_MODE_FAST;
-    if (fast && pixels > ctx->queue_cap) {
+    unsigned char *sp = nullptr;
+    if (use_static) {
+        const int tile_px = 1 << vr::kRangeShift;
+        const size_t tile_count = (size_t)((width + tile_px - 1) / tile_px) * (size_t)((height + tile_px - 1) / tile_px);
+        if (pixels > static_scratch::kMaxPixels || tile_count > static_scratch::kMaxTiles)
+            return fail(ctx, VR_ERR_ARG, "frame too large for the static scratch: at most " + std::to_string(static_scratch::kMaxPixels) +
+                                             " pixels and " + std::to_string(static_scratch::kMaxTiles) + " 8x8 tiles");
+        sp = ctx->device < static_scratch::kMaxDevices ? g_scratch_ptr[ctx->device] : nullptr;
+        if (!sp) return fail(ctx, VR_ERR_STATE, "no static scratch on this device");
+    }
+    if (!use_static && fast && pixels > ctx->queue_cap) {
         if (ctx->queue) (void)hipFree(ctx->queue);
         if (ctx->long_queue) (void)hipFree(ctx->long_queue);
         ctx->queue = nullptr;
@@ -932,7 +975,7 @@ static int render_impl(vr_ctx *ctx, int width, int height, int x0, int y0, int x
         VR_HIP(ctx, hipMalloc(&ctx->long_queue, pixels * sizeof(vr::LongRay)));
         ctx->queue_cap = pixels;
     }
-    if (fast) {
+    if (fast && !use_static) {
         const int tile_px = 1 << vr::kRangeShift;
         const size_t tile_count = (size_t)((width + tile_px - 1) / tile_px) * (size_t)((height + tile_px - 1) / tile_px);
         if (tile_count > ctx->tiles_cap) {
@@ -945,11 +988,16 @@ static int render_impl(vr_ctx *ctx, int width, int height, int x0, int y0, int x
     }
     // Two frames in flight: only for fast frames into device memory without counters.  Every other
     // frame first lets the frames in flight finish and then runs on the one stream.
-    const bool piped = fast && out_is_device && !want_stats && ctx->pipeline_depth == 2;
+    const bool piped = fast && out_is_device && !want_stats && ctx->pipeline_depth == 2 && !use_static;
     if (!piped || ctx->occupancy_dirty) drain(ctx);
     if (ctx->mode != VR_MODE_REFERENCE_ORDER)
         if (int rc = refresh_occupancy(ctx)) return rc;
     FrameBuffers fb{ctx->counters, ctx->queue, ctx->long_queue, ctx->tiles, ctx->stream, nullptr};
+    if (use_static)
+        fb = FrameBuffers{reinterpret_cast<vr::Counters *>(sp + static_scratch::kCountersAt),
+                          reinterpret_cast<uint32_t *>(sp + static_scratch::kQueueAt),
+                          reinterpret_cast<vr::LongRay *>(sp + static_scratch::kLongAt),
+                          reinterpret_cast<uint2 *>(sp + static_scratch::kTilesAt), ctx->stream, nullptr};
     int set = 0;
     if (piped) {
         set = (int)(ctx->pipe_index++ & 1u);
@@ -1051,6 +1099,18 @@ int vr_render(vr_ctx *ctx, int width, int height, uint8_t *out, int out_is_devic
 {
     return render_impl(ctx, width, height, 0, 0, width, height, 0, 1, out, out_is_device, stats);
 }
+
+int vr_render_static(vr_ctx *ctx, int width, int height, uint8_t *d_out)
+{
+    if (!ctx) return VR_ERR_ARG;
+    const int mode = ctx->mode;
+    ctx->mode = VR_MODE_FAST;
+    const int rc = render_impl(ctx, width, height, 0, 0, width, height, 0, 1, d_out, 1, nullptr, true);
+    ctx->mode = mode;
+    return rc;
+}
+
+int vr_static_max_pixels(void) { return (int)static_scratch::kMaxPixels; }
 
 int vr_render_bands(vr_ctx *ctx, int width, int height, int part, int parts, uint8_t *out, int out_is_device, vr_stats *stats)
 {
