@@ -29,4 +29,9 @@ for step in (0, 45, 90, 200):
     print("step %3d  hit rays %d  taps/ray %.2f  look-ups/ray %.2f  long rays %.2f%%  replayed %.3f%%  bricks %d  kernel %.3f ms" % (
         step, hit, st["samples_evaluated"] / hit, st["cells_read"] / hit, 100.0 * st["long_rays"] / hit,
         100.0 * st["replay_rays"] / hit, st["bricks_touched"], st["kernel_ms"]))
+    lane_taps = st["samples_evaluated"] - st["long_samples"] - st["replay_samples"]
+    print("   taps: lane march %.1f M, wave march %.1f M (%.0f per handed-over ray), replay %.1f M; bricks of the lane march alone %d" % (
+        lane_taps / 1e6, st["long_samples"] / 1e6, st["long_samples"] / max(1, st["long_rays"]), st["replay_samples"] / 1e6, st["main_bricks"]))
+    print("   rays by taps in the lane march (bin k: 2^k - 1 .. 2^(k+1) - 2):", [c for c in st["rays_by_lane_taps"][:12]])
+    print("   handed-over rays by taps in the wave march:                     ", [c for c in st["rays_by_wave_taps"][:16]])
 ctx.close()

@@ -499,7 +499,7 @@ int vr_create(int device, vr_ctx **out)
     if (const char *e = std::getenv("VR_TILE_CLIP")) ctx->tile_clip = std::atoi(e) != 0;
     if (const char *e = std::getenv("VR_LANE_BUDGET")) ctx->lane_budget = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("VR_PARTIAL_BUDGET")) ctx->partial_budget = std::max(1, std::atoi(e));
-    if (const char *e = std::getenv("VR_TAIL_BLOCKS")) ctx->tail_blocks = std::max(64, std::min(65536, std::atoi(e)));
+    if (const char *e = std::getenv("VR_TAIL_BLOCKS")) ctx->tail_blocks = std::max(64, std::min(65536, std::atoi(e))) & ~31;   // a multiple of 32: for_queue_entries
     if (const char *e = std::getenv("VR_WAVES_PER_BLOCK")) ctx->waves_per_block = std::max(1, std::min(4, std::atoi(e)));
     if (device < static_scratch::kMaxDevices && !g_scratch_ptr[device]) {
         // this GPU's copy of the static scratch array (hipSetDevice(device) above made the GPU current)

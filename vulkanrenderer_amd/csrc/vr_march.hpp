@@ -965,7 +965,7 @@ struct LongRay {
 // latency-bound chain a single slow ray (one that grazes the object without ever becoming opaque)
 // can keep its wave alive for.
 #ifndef VR_LANE_BUDGET
-#define VR_LANE_BUDGET 112
+#define VR_LANE_BUDGET 128
 #endif
 constexpr int kLaneBudget = VR_LANE_BUDGET;
 #ifndef VR_DECIDE_EVERY
@@ -1565,6 +1565,36 @@ __device__ __forceinline__ bool continue_ray(const VolumeView &vol, const FrameP
     return decided;
 }
 
+// Which entries of a hand-over queue a wave of a wave-per-ray kernel takes.  The lane march appends
+// the rays of a wave (one 8x8 pixel tile) in one piece, so neighbours in the queue are neighbours on
+// the screen and walk the same bricks.  Workgroups are dealt round-robin to the chip's eight XCDs,
+// each with an L2 of its own (blocks b and b + 8 share one): were consecutive entries handed to
+// consecutive blocks, every XCD would fetch every tile's bricks from memory for itself.  Instead a run of
+// consecutive entries stays on one XCD: four blocks of that XCD take a quarter of the run each, and the
+// four waves of a block work on four neighbouring entries at any time.  A wave takes up to four entries
+// of a run in turn (one when the queue is short enough for every entry to have a wave of its own).
+// Calls f(entry) for each entry of this wave; the waves of the grid together cover [0, entries) once.
+// Correct for any placement of the blocks, only the cache hit rate depends on it.  gridDim.x must be a
+// multiple of 32.
+template <typename F>
+__device__ __forceinline__ void for_queue_entries(uint32_t entries, F f)
+{
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;       // slot: index among the blocks of this XCD
+    const uint32_t quads = gridDim.x >> 5;                               // runs one XCD works on at a time
+    const uint32_t all_waves = gridDim.x * 4u;
+    const uint32_t per_wave = min(4u, max(1u, (entries + all_waves - 1u) / all_waves));
+    const uint32_t run = 16u * per_wave;
+    const uint32_t runs = (entries + run - 1u) / run;
+    for (uint32_t q = slot >> 2; q * 8u + xcd < runs; q += quads) {
+        const uint32_t first = (q * 8u + xcd) * run + (slot & 3u) * 4u * per_wave;
+        for (uint32_t k = 0; k < per_wave; k++) {
+            const uint32_t entry = first + k * 4u + wave;
+            if (entry < entries) f(entry);
+        }
+    }
+}
+
 // The rays k_march_fast ran out of lane budget on, one wave per ray; rays still undecided at the back
 // join the replay queue.
 #ifndef VR_LONG_MIN_WAVES
@@ -1580,9 +1610,7 @@ __global__ __launch_bounds__(256, VR_LONG_MIN_WAVES) void k_march_long(VolumeVie
     stage_lut(s_lut, lut, border);
     const Decider dec(info);
     const int lane = threadIdx.x & 63;
-    const uint32_t waves = gridDim.x * 4u;
-    const uint32_t entries = ctr->long_count;
-    for (uint32_t entry = blockIdx.x * 4u + (threadIdx.x >> 6); entry < entries; entry += waves) {
+    for_queue_entries(ctr->long_count, [&](uint32_t entry) {
         const LongRay e = long_queue[entry];
         uint32_t rgba;
         const bool decided = continue_ray<T, STATS, false, SHADE>(vol, fp, s_lut, dec, ctr, touched, e, rgba);
@@ -1590,7 +1618,7 @@ __global__ __launch_bounds__(256, VR_LONG_MIN_WAVES) void k_march_long(VolumeVie
             if (decided) out[e.pixel_id] = rgba;
             else queue[atomicAdd(&ctr->replay_count, 1u)] = e.pixel_id;
         }
-    }
+    });
 }
 
 // The rays neither march could decide, re-marched in reference order, one wave per ray.
@@ -1604,10 +1632,9 @@ __global__ __launch_bounds__(256) void k_replay_exact(VolumeView vol, FrameParam
     __shared__ float4 s_lut[kLutLds];
     stage_lut(s_lut, lut, border);
     const Decider dec(info);
-    const uint32_t waves = gridDim.x * 4u;
-    const uint32_t entries = ctr->replay_count;
-    for (uint32_t entry = blockIdx.x * 4u + (threadIdx.x >> 6); entry < entries; entry += waves)
+    for_queue_entries(ctr->replay_count, [&](uint32_t entry) {
         replay_ray<T, STATS, false, SHADE>(vol, fp, s_lut, dec, out, ctr, touched, queue[entry], tiles, tiles_x);
+    });
 }
 
 // Number of set bits of a bit map, added to *total (counting builds: bricks touched so far).

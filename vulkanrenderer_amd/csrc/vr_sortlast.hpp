@@ -95,13 +95,11 @@ __global__ __launch_bounds__(256) void k_partial_long(VolumeView vol, FrameParam
     __shared__ float4 s_lut[kLutLds];
     stage_lut(s_lut, lut, border);
     const Decider dec(info);
-    const uint32_t waves = gridDim.x * 4u;
-    const uint32_t entries = ctr->long_count;
-    for (uint32_t entry = blockIdx.x * 4u + (threadIdx.x >> 6); entry < entries; entry += waves) {
+    for_queue_entries(ctr->long_count, [&](uint32_t entry) {
         const LongRay e = long_queue[entry];
         uint32_t rgba;
         continue_ray<T, false, true>(vol, fp, s_lut, dec, ctr, nullptr, e, rgba, out);
-    }
+    });
 }
 
 // ---- combining partial results --------------------------------------------------------------------
