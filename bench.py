@@ -1,20 +1,34 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Gsamples/s of the volume ray-march, 2048^3 uint16 phantom at 3840x2160.
+"""Headline benchmark: Gsamples/s and frames/s of the volume ray-march.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c1|c2|c3|c4|c5]
 
-A step is one frame of the orbit (camera h = -180 deg + step * 1 deg, v = 20 deg) rendered by the
-HIP path through the C ABI with the volume resident in HBM.  With N > 1 (launched by
-torch.distributed.run, one rank per GPU) the frame is split sort-first into 16-row bands, the
-volume is replicated, and the bands are gathered on rank 0 over RCCL inside the timed region.
-`value` counts the taps the reference shader would execute for these frames (rays that hit the box
-x (samples + 2)) per second of wall time, max over ranks; total work is fixed, so scaling is strong.
-Rank 0 prints one JSON line.
+A step is one frame rendered by the HIP path through the C ABI with the volume resident in HBM and
+the frame left in device memory.  The configurations are the benchmark's named workloads:
+
+    c1  256^3 uint8 phantom,  512x512,   200 samples/ray, fixed camera (30, 20 degrees)
+    c2  512^3 uint16 phantom, 1920x1080, half-voxel sampling, orbit
+    c3  1024^3 uint16,        3840x2160, orbit                       (sort-first when N > 1)
+    c4  2048^3 uint16,        3840x2160, 360-frame orbit (default: the configuration the metric is quoted on)
+    c5  sort-last: the volume cut into one box of bricks per GPU, 16 GiB of voxels per GPU
+        (2048^3 on 1 GPU ... 4096^3 on 8), 3840x2160, partial images merged over RCCL
+
+With N > 1 and c1-c4 the frame is split sort-first into 16-row bands, the volume is replicated and
+the bands are gathered on rank 0 over RCCL inside the timed region; total work is fixed, so the
+scaling is strong.  With c5 every rank holds its box only; the volume grows with N (weak scaling).
+`value` counts the taps the reference shader would execute for the timed frames (rays that hit the
+box x (samples + 2)) per second of wall time, max over ranks.  Rank 0 prints one JSON line.
+
+Launch: `python bench.py --gpus N` starts its N ranks itself (torch.distributed.run as a child
+process, before this process touches a GPU); under a launcher that has already set WORLD_SIZE it is
+one of the ranks.
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,6 +41,17 @@ if ROOT not in sys.path:
 TF_X = (0.0, 120.0, 300.0, 483.0)
 TF_GRAPHS = [list(zip(TF_X, c)) for c in ((0, .9, 1, 1), (0, .3, .8, 1), (0, .1, .5, 1), (0, 0, .05, .6))]
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+METRIC = "Gsamples/s + frames/s, 2048^3 u16 @ 4K, 1/2/4/8 MI355X; % HBM roofline"
+
+CONFIGS = {
+    "c1": dict(volume=256, dtype=1, width=512, height=512, samples=200, camera="fixed", split="sort-first"),
+    "c2": dict(volume=512, dtype=2, width=1920, height=1080, samples=None, camera="orbit", split="sort-first"),
+    "c3": dict(volume=1024, dtype=2, width=3840, height=2160, samples=None, camera="orbit", split="sort-first"),
+    "c4": dict(volume=2048, dtype=2, width=3840, height=2160, samples=None, camera="orbit", split="sort-first"),
+    "c5": dict(volume=None, dtype=2, width=3840, height=2160, samples=None, camera="orbit", split="sort-last"),
+}
+# c5: 16 GiB of uint16 voxels per GPU
+SORT_LAST_VOLUME = {1: 2048, 2: 2560, 4: 3200, 8: 4096}
 
 
 def samples_for(n):
@@ -38,39 +63,59 @@ def orbit_camera(step):
     return math.radians(-180.0 + (step % 360) * 1.0), math.radians(20.0)
 
 
-def cpu_baseline(threads=0):
-    """The CPU checker (a port of the reference shader) timed on a bounded sample of the workload:
-    512^3 uint16 phantom, 1920x1080, half-voxel sampling, one whole frame (about 10 s on 16 cores)."""
+def fixed_camera(step):
+    return math.radians(30.0), math.radians(20.0)
+
+
+def cpu_baseline(config="c2", threads=0):
+    """The CPU checker (a port of the reference shader) timed on one whole frame of a small configuration:
+    c2 = 512^3 uint16, 1920x1080, half-voxel sampling (about 10 s on 16 cores); c1 = 256^3 uint8, 512x512,
+    200 samples (the configuration the CPU leg is quoted on; well under a second)."""
     from oracle import vr_oracle as o
     o.build()
-    n, w, h = 512, 1920, 1080
-    samples = samples_for(n)
-    vol, _ = o.normalize(o.phantom(n, np.uint16))
+    cfg = CONFIGS[config]
+    n, w, h = cfg["volume"], cfg["width"], cfg["height"]
+    samples = cfg["samples"] or samples_for(n)
+    vol, _ = o.normalize(o.phantom(n, np.uint8 if cfg["dtype"] == 1 else np.uint16))
     lut = np.zeros((256, 4), np.float32)
     o.lut_update(lut, TF_GRAPHS)
     cam = (math.radians(30.0), math.radians(20.0))
     vp, m = o.camera(cam[0], cam[1], w, h)
     rows = (0, h)
-    t0 = time.perf_counter()
-    img, col = o.render(vol, lut, vp[4:8], m, w, h, samples, rows=rows, want_colour=True, threads=threads)
-    dt = time.perf_counter() - t0
-    strip_hits = o.count_hits(vp[4:8], m, w, h, rows=rows)   # every such ray takes samples + 2 taps
-    taps = strip_hits * (samples + 2)
-    return {"value": taps / dt / 1e9, "unit": "Gsamples/s", "cores": o.threads() if threads <= 0 else threads,
+    reps = 3 if config == "c1" else 1
+    best = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        o.render(vol, lut, vp[4:8], m, w, h, samples, rows=rows, want_colour=True, threads=threads)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    hits = o.count_hits(vp[4:8], m, w, h, rows=rows)   # every such ray takes samples + 2 taps
+    taps = hits * (samples + 2)
+    return {"value": taps / best / 1e9, "unit": "Gsamples/s", "cores": o.threads() if threads <= 0 else threads,
             "kind": "port",
-            "sample": "CPU restatement of the shader (oracle/, OpenMP): 512^3 u16 phantom, 1920x1080, %d samples/ray, "
-                      "rows %d-%d (%d rays hit, %.2f s)" % (samples, rows[0], rows[1] - 1, strip_hits, dt)}
+            "sample": "CPU restatement of the shader (oracle/, OpenMP), configuration %s: %d^3 %s phantom, %dx%d, %d samples/ray, "
+                      "one whole frame (%d rays hit, %.2f s%s)" % (config, n, "u8" if cfg["dtype"] == 1 else "u16", w, h, samples, hits, best,
+                                                                 ", best of %d" % reps if reps > 1 else "")}
 
 
-def main():
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=360, help="frames timed; 360 = the whole orbit at 1 degree a step")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--volume", type=int, default=2048, help="phantom edge length in voxels")
-    ap.add_argument("--width", type=int, default=3840)
-    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c4")
+    ap.add_argument("--volume", type=int, default=None, help="phantom edge length in voxels (default: the configuration's)")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--mode", choices=("fast", "reference", "reference_skip"), default="fast")
+    ap.add_argument("--schedule", choices=("direct_send", "binary_swap"), default="binary_swap",
+                    help="c5: how the partial images are exchanged (binary swap is the schedule the benchmark names)")
     ap.add_argument("--stats-frames", type=int, default=12, help="frames measured with counters for the roofline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tune", action="store_true",
@@ -78,47 +123,107 @@ def main():
                          "value is the one measured best for the default workload")
     ap.add_argument("--shading", action="store_true",
                     help="switch on the shader's commented-out lighting (not the headline workload: the reference renders without it)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
-    if os.environ.get("VR_BENCH_WATCHDOG"):
-        # rehearsals only: a rank stuck for this many seconds prints its Python stacks and exits
-        import faulthandler
-        log = open(os.environ["VR_BENCH_WATCHDOG_FILE"] + "." + os.environ.get("RANK", "0"), "w") if os.environ.get("VR_BENCH_WATCHDOG_FILE") else sys.stderr
-        faulthandler.dump_traceback_later(float(os.environ["VR_BENCH_WATCHDOG"]), exit=True, file=log)
-    import torch
-    import torch.distributed as dist
 
+def launch_ranks(args):
+    """--gpus N without a launcher: start the N ranks as a child process tree.  Nothing here has touched
+    a GPU (torch is not even imported), so no GPU state is carried into the children."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+class Setup:
+    """What both splits share: process group, device, configuration."""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, self.world))
+        # Rehearsal switches (not used by a normal run): several ranks on one GPU, exchanging over gloo
+        # through host memory, to exercise the multi-rank control flow where only one GPU is at hand.
+        self.backend = os.environ.get("VR_BENCH_BACKEND", "nccl")
+        if os.environ.get("VR_BENCH_ONE_DEVICE"):
+            local_rank = 0
+        self.local_rank = local_rank
+        torch.cuda.set_device(local_rank)
+        self.device = torch.device("cuda", local_rank)
+        if self.world > 1:
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.device)
+            else:
+                dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
+        cfg = dict(CONFIGS[args.config])
+        if cfg["volume"] is None:
+            if self.world not in SORT_LAST_VOLUME and args.volume is None:
+                raise SystemExit("c5 is defined for 1, 2, 4 or 8 GPUs (or give --volume)")
+            cfg["volume"] = SORT_LAST_VOLUME.get(self.world)
+        self.overridden = [k for k in ("volume", "width", "height") if getattr(args, k) is not None]
+        for k in self.overridden:
+            cfg[k] = getattr(args, k)
+        if cfg["samples"] is None:
+            cfg["samples"] = samples_for(cfg["volume"])
+        self.cfg = cfg
+        self.camera = fixed_camera if cfg["camera"] == "fixed" else orbit_camera
+
+    def fence(self, ctx):
+        ctx.synchronize()
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, seconds):
+        if self.world == 1:
+            return seconds
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device=self.device if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def workload(self, args, extra):
+        c = self.cfg
+        cam = "fixed camera (30, 20 degrees)" if c["camera"] == "fixed" else \
+            "%d frames of the 360-frame orbit at 1 deg/step" % args.steps if args.steps < 360 else \
+            "%d frames round the 360-frame orbit at 1 deg/step" % args.steps
+        text = "%s: %d^3 %s Shepp-Logan phantom, %dx%d, %d samples/ray%s, 4-point transfer function, %s, mode %s%s%s" % (
+            args.config, c["volume"], "uint8" if c["dtype"] == 1 else "uint16", c["width"], c["height"], c["samples"],
+            " (half-voxel on the diagonal)" if CONFIGS[args.config]["samples"] is None else "", cam, args.mode,
+            ", gradient lighting on" if args.shading else "", extra)
+        if self.overridden:
+            text += " [not the named configuration: %s overridden]" % ", ".join(self.overridden)
+        return text
+
+
+def counters_of_profiles(key):
+    """Counter figures of the march kernel collected with rocprofv3 --pmc on the configuration `key`
+    (profiles/traffic.json, written from the round's PMC passes); None where nothing was collected."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        return json.load(open(path)).get(key)
+    except Exception:
+        return None
+
+
+def run_sort_first(args, su):
+    torch = su.torch
     import vulkanrenderer_amd as vr
     from vulkanrenderer_amd.sortfirst import SortFirstFrame
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
-    # Rehearsal switches (not used by a normal run): several ranks on one GPU, exchanging over gloo
-    # through host memory, to exercise the multi-rank control flow where only one GPU is at hand.
-    backend = os.environ.get("VR_BENCH_BACKEND", "nccl")
-    if os.environ.get("VR_BENCH_ONE_DEVICE"):
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-
-    n, w, h = args.volume, args.width, args.height
-    samples = samples_for(n)
+    c, world, rank, device = su.cfg, su.world, su.rank, su.device
+    n, w, h, samples = c["volume"], c["width"], c["height"], c["samples"]
     mode = {"fast": vr.MODE_FAST, "reference": vr.MODE_REFERENCE_ORDER, "reference_skip": vr.MODE_REFERENCE_SKIP}[args.mode]
 
-    ctx = vr.VolumeRenderer(local_rank)
+    ctx = vr.VolumeRenderer(su.local_rank)
     t_setup = time.perf_counter()
-    raw = torch.empty(n ** 3, dtype=torch.int16, device=device)
+    raw = torch.empty(n ** 3, dtype=torch.uint8 if c["dtype"] == 1 else torch.int16, device=device)
     torch.cuda.synchronize()
-    ctx.phantom_generate_device(raw.data_ptr(), vr.DTYPE_U16, n)
-    ctx.upload_volume_device(raw.data_ptr(), vr.DTYPE_U16, n, n, n)   # bricks + macrocells, volume replicated per rank
+    ctx.phantom_generate_device(raw.data_ptr(), c["dtype"], n)
+    ctx.upload_volume_device(raw.data_ptr(), c["dtype"], n, n, n)   # bricks + macrocells, volume replicated per rank
     ctx.synchronize()
     del raw
     torch.cuda.empty_cache()
@@ -130,22 +235,23 @@ def main():
     lane_budget = None
     if args.tune and mode == vr.MODE_FAST:
         # part of the set-up: the library measures its one tuning parameter on a view of the orbit
-        ctx.set_camera(*orbit_camera(45))
+        ctx.set_camera(*su.camera(45))
         lane_budget = ctx.tune(w, h, rank if world > 1 else 0, world if world > 1 else 1)
     t_setup = time.perf_counter() - t_setup
 
-    sf = SortFirstFrame(w, h, rank, world, device, host_staging=backend != "nccl")
+    sf = SortFirstFrame(w, h, rank, world, device, host_staging=su.backend != "nccl")
     lib_stream = torch.cuda.ExternalStream(ctx.stream, device=device)
     target = sf.frame if world == 1 else sf.local
     # Two frames in flight: the few rays a frame's main march hands over are finished beside the next
     # frame's march, so consecutive frames go to two output buffers in turn.  Every frame is complete
-    # when the timed region ends (fence() below waits for both streams).
+    # when the timed region ends (fence() waits for both streams).
     ctx.set_pipeline(2)
     targets = [target, torch.zeros_like(target)] if world == 1 else None
+    torch.cuda.synchronize()     # the fill ran on torch's stream, the frames are written on the context's
     gathered = [None, None]      # per band buffer: event after the gather that last read it
 
     def frame(step):
-        ctx.set_camera(*orbit_camera(step))
+        ctx.set_camera(*su.camera(step))
         if world == 1:
             ctx.render_bands(w, h, 0, 1, ptr=targets[step & 1].data_ptr())
             return
@@ -160,34 +266,24 @@ def main():
         ev.record(torch.cuda.current_stream())
         gathered[turn] = ev
 
-    def fence():
-        ctx.synchronize()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
-
     for i in range(args.warmup):
         frame(i)
-    fence()
+    su.fence(ctx)
     t0 = time.perf_counter()
     for i in range(args.steps):
         frame(i)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    su.fence(ctx)
+    elapsed = su.max_over_ranks(time.perf_counter() - t0)
     kernel_ms = ctx.march_kernel_times(min(args.steps, 1024))
 
-    # latency of single frames (untimed pass, one frame at a time on one stream): the spread over the orbit
+    # latency of single frames (untimed pass, one frame at a time on one stream): the spread over the views
     latency = None
+    frame_ms = None
     if world == 1:
         ctx.set_pipeline(1)
         marks = []
         for i in range(args.steps):
-            ctx.set_camera(*orbit_camera(i))
+            ctx.set_camera(*su.camera(i))
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(lib_stream)
             ctx.render_bands(w, h, 0, 1, ptr=target.data_ptr())
@@ -195,22 +291,29 @@ def main():
             marks.append((a, b))
         ctx.synchronize()
         ms = np.array([a.elapsed_time(b) for a, b in marks])
-        latency = {"mean": float(ms.mean()), "p5": float(np.percentile(ms, 5)), "p50": float(np.percentile(ms, 50)),
+        frame_ms = float(ms.mean())
+        latency = {"mean": frame_ms, "p5": float(np.percentile(ms, 5)), "p50": float(np.percentile(ms, 50)),
                    "p95": float(np.percentile(ms, 95)), "frames": int(ms.size)}
         ctx.set_pipeline(2)
 
     # work of the timed frames: what the reference shader would execute
     nominal = 0
     if rank == 0:
+        per_view = {}
         for i in range(args.steps):
-            ctx.set_camera(*orbit_camera(i))
-            nominal += ctx.count_hit_rays(w, h) * (samples + 2)
+            cam = su.camera(i)
+            if cam not in per_view:
+                ctx.set_camera(*cam)
+                per_view[cam] = ctx.count_hit_rays(w, h) * (samples + 2)
+            nominal += per_view[cam]
 
     # counters of a few frames of this rank's share (untimed): algorithmic bytes of the march kernel
     stats_steps = sorted(set(int(round(k * (args.steps - 1) / max(1, args.stats_frames - 1))) for k in range(args.stats_frames))) if args.steps > 1 else [0]
-    agg = {"algorithmic_bytes": 0, "samples_evaluated": 0, "bricks_touched": 0, "replay_rays": 0, "rays_hit": 0}
+    keys = ("algorithmic_bytes", "samples_evaluated", "bricks_touched", "main_bricks", "replay_rays", "long_rays", "rays_hit",
+            "long_samples", "replay_samples")
+    agg = dict.fromkeys(keys, 0)
     for s in stats_steps:
-        ctx.set_camera(*orbit_camera(s))
+        ctx.set_camera(*su.camera(s))
         st = ctx.render_bands(w, h, rank if world > 1 else 0, world if world > 1 else 1,
                               ptr=(target if world == 1 else sf.local).data_ptr(), stats=True)
         for k in agg:
@@ -219,19 +322,55 @@ def main():
     for k in agg:
         agg[k] /= len(stats_steps)
 
+    line = None
     if rank == 0:
         kern_s = float(np.mean(kernel_ms)) / 1e3
-        achieved = agg["algorithmic_bytes"] / kern_s / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        # the counters were collected on whole-frame launches: no figure for a rank's share of the bands
-        if world == 1 and os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("%d_%dx%d_%s%s" % (n, w, h, args.mode, "_shaded" if args.shading else ""))
-            except Exception:
-                traffic = None
+        fast = args.mode == "fast"
+        brick_bytes = 512 * c["dtype"]
+        # bytes the dominant kernel needs: the bricks IT touches (the tail kernels' bricks are not its), the
+        # occupancy tables, the table and the frame it stores
+        overhead = agg["algorithmic_bytes"] - brick_bytes * agg["bricks_touched"]
+        kernel_bytes = brick_bytes * (agg["main_bricks"] if fast else agg["bricks_touched"]) + overhead
+        achieved = kernel_bytes / kern_s / 1e9
+        # PMC figures exist for whole-frame launches of configurations profiled with rocprofv3
+        pmc = counters_of_profiles("%d_%dx%d_%s%s" % (n, w, h, args.mode, "_shaded" if args.shading else "")) if world == 1 else None
+        if isinstance(pmc, (int, float)):
+            pmc = {"traffic": pmc}
+        pmc = pmc or {}
+        roofline = {
+            "bound": "hbm",
+            "kernel": "k_march_fast" if fast else "k_march_exact",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": pmc.get("traffic"),
+            "traffic_source": pmc.get("source", "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE passes of this workload)") if pmc.get("traffic") else None,
+            # what the counters say limits the kernel: not the memory system
+            "limited_by": pmc.get("limited_by", "vector ALU under lane divergence"),
+            "valu_busy": pmc.get("valu_busy"),
+            "lanes_active": pmc.get("lanes_active"),
+            "l2_hit": pmc.get("l2_hit"),
+            "algorithmic_bytes_per_launch": kernel_bytes,
+            "kernel_ms_avg": kern_s * 1e3,
+            "kernel_ms_min": float(np.min(kernel_ms)),
+            "kernel_ms_max": float(np.max(kernel_ms)),
+            # the same bytes over the device time of a whole frame (all kernels, one frame at a time)
+            "frame_algorithmic_bytes": agg["algorithmic_bytes"],
+            "frac_whole_frame": (agg["algorithmic_bytes"] / (frame_ms / 1e3) / 1e9 / HBM_PEAK_GBS) if frame_ms else None,
+            "frac_per_step": agg["algorithmic_bytes"] / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
+            "bricks_touched_per_launch": agg["main_bricks"] if fast else agg["bricks_touched"],
+            "bricks_touched_per_frame": agg["bricks_touched"],
+            "samples_evaluated_per_frame": agg["samples_evaluated"],
+            "samples_evaluated_per_launch": agg["samples_evaluated"] - agg["long_samples"] - agg["replay_samples"],
+            "evaluated_gsamples_per_s": (agg["samples_evaluated"] - agg["long_samples"] - agg["replay_samples"]) / kern_s / 1e9,
+            "gather_gb_per_s": 16.0 * (agg["samples_evaluated"] - agg["long_samples"] - agg["replay_samples"]) / kern_s / 1e9,
+            "handed_over_ray_fraction": agg["long_rays"] / max(1.0, agg["rays_hit"]),
+            "replay_ray_fraction": agg["replay_rays"] / max(1.0, agg["rays_hit"]),
+            "frames_with_counters": len(stats_steps),
+        }
         line = {
-            "metric": "Gsamples/s + frames/s, 2048^3 u16 @ 4K, 1/2/4/8 MI355X; % HBM roofline",
+            "metric": METRIC,
             "value": nominal / elapsed / 1e9,
             "unit": "Gsamples/s",
             "n_gpus": world,
@@ -246,8 +385,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "%d^3 uint16 Shepp-Logan phantom, %dx%d, %d samples/ray (half-voxel on the diagonal), 4-point "
-                            "transfer function, 360-frame orbit at 1 deg/step, mode %s%s" % (n, w, h, samples, args.mode, ", gradient lighting on" if args.shading else ""),
+                "workload": su.workload(args, ""),
+                "name": args.config,
                 "volume": [n, n, n], "image": [w, h], "samples_per_ray": samples, "mode": args.mode,
                 "parallelism": "sort-first x%d (16-row bands, replicated volume, RCCL gather)" % world if world > 1 else "single GPU",
                 "frames_in_flight": 2,
@@ -255,33 +394,142 @@ def main():
                 "lane_budget": lane_budget,
                 "setup_s": round(t_setup, 2),
             },
+            "roofline": roofline,
+        }
+    ctx.close()
+    return line
+
+
+def run_sort_last(args, su):
+    torch = su.torch
+    import vulkanrenderer_amd as vr
+    from vulkanrenderer_amd import sortlast as sl
+    c, world, rank, device = su.cfg, su.world, su.rank, su.device
+    n, w, h, samples = c["volume"], c["width"], c["height"], c["samples"]
+    if args.mode != "fast" or args.shading:
+        raise SystemExit("c5 renders partial images: no --mode, no --shading")
+    grid = sl.box_grid(world)
+    box = sl.box_of_rank(rank, grid)
+    schedule = args.schedule
+    ctx = vr.VolumeRenderer(su.local_rank)
+    t_setup = time.perf_counter()
+    lo, hi = sl.upload_phantom_box(ctx, n, c["dtype"], grid, box, device)
+    torch.cuda.empty_cache()
+    ctx.update_transfer_function(TF_GRAPHS, reset_state=True)
+    ctx.set_sampling(samples, (0.0, 0.0, 0.0, 0.0))
+    t_setup = time.perf_counter() - t_setup
+    engine = sl.HipEngine(ctx, w, h)
+    fr = sl.SortLastFrame(engine, w, h, rank, world, device, grid=grid, schedule=schedule, host_staging=su.backend != "nccl")
+
+    def frame(step, mark=None):
+        ctx.set_camera(*su.camera(step))
+        return fr.render(mark=mark)
+
+    for i in range(args.warmup):
+        frame(i)
+    su.fence(ctx)
+    t0 = time.perf_counter()
+    remarched = 0
+    for i in range(args.steps):
+        frame(i)
+        remarched += fr.remarched
+    su.fence(ctx)
+    elapsed = su.max_over_ranks(time.perf_counter() - t0)
+
+    # device time per stage on this rank (untimed pass over a few views, events on the context's stream)
+    stage_names = ("partial_march", "exchange_merge", "decide", "remarch", "gather")
+    views = sorted(set(int(round(k * (args.steps - 1) / max(1, min(args.stats_frames, args.steps) - 1))) for k in range(min(args.stats_frames, args.steps)))) \
+        if args.steps > 1 else [0]
+    stage_ms = np.zeros((len(views), len(stage_names)))
+    for vi, s in enumerate(views):
+        evs = []
+
+        def mark(_name):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(engine.stream)
+            evs.append(e)
+        mark("start")
+        frame(s, mark=mark)
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        for k in range(len(stage_names)):
+            stage_ms[vi, k] = evs[k].elapsed_time(evs[k + 1])
+    mine = torch.tensor(stage_ms.mean(axis=0), dtype=torch.float64)
+    per_rank = [mine.clone() for _ in range(world)]
+    if world > 1:
+        if su.backend == "nccl":
+            got = [torch.zeros_like(mine, device=device) for _ in range(world)]
+            su.dist.all_gather(got, mine.to(device))
+            per_rank = [g.cpu() for g in got]
+        else:
+            su.dist.all_gather(per_rank, mine)
+    nominal = 0
+    if rank == 0:
+        for i in range(args.steps):
+            ctx.set_camera(*su.camera(i))
+            nominal += ctx.count_hit_rays(w, h) * (samples + 2)
+    line = None
+    if rank == 0:
+        stages = {name: {"mean_over_ranks_ms": float(np.mean([p[k] for p in per_rank])), "max_over_ranks_ms": float(np.max([p[k] for p in per_rank]))}
+                  for k, name in enumerate(stage_names)}
+        march = [float(p[0]) for p in per_rank]
+        line = {
+            "metric": METRIC,
+            "value": nominal / elapsed / 1e9,
+            "unit": "Gsamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "frames_per_s": args.steps / elapsed,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": su.workload(args, ", sort-last over %d box%s (%dx%dx%d), %s" % (world, "" if world == 1 else "es", grid[0], grid[1], grid[2], schedule.replace("_", " "))),
+                "name": args.config,
+                "volume": [n, n, n], "image": [w, h], "samples_per_ray": samples,
+                "parallelism": "sort-last x%d (boxes of bricks %dx%dx%d, %s over RCCL, byte-exact re-march of undecided pixels)" % (world, grid[0], grid[1], grid[2], schedule),
+                "bricks_of_rank0": [list(lo), list(hi)],
+                "setup_s": round(t_setup, 2),
+            },
+            "stages": stages,
+            "partial_march_ms_per_rank": march,
+            "partial_march_max_over_mean": max(march) / max(1e-9, float(np.mean(march))),
+            "remarched_pixel_fraction": remarched / float(args.steps) / float(w * h),
+            "exchange_bytes_per_rank": (world - 1) * fr.span * 20,
             "roofline": {
-                "bound": "hbm",
-                "kernel": "k_march_fast" if args.mode == "fast" else "k_march_exact",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "algorithmic_bytes_per_launch": agg["algorithmic_bytes"],
-                "kernel_ms_avg": kern_s * 1e3,
-                "kernel_ms_min": float(np.min(kernel_ms)),
-                "kernel_ms_max": float(np.max(kernel_ms)),
-                "bricks_touched_per_launch": agg["bricks_touched"],
-                "samples_evaluated_per_launch": agg["samples_evaluated"],
-                "evaluated_gsamples_per_s": agg["samples_evaluated"] / kern_s / 1e9,
-                "gather_gb_per_s": 16.0 * agg["samples_evaluated"] / kern_s / 1e9,
-                "replay_ray_fraction": agg["replay_rays"] / max(1.0, agg["rays_hit"]),
-                "frames_with_counters": len(stats_steps),
+                "bound": "hbm", "kernel": "k_march_partial", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                "note": "the partial march has no counting variant: no algorithmic byte count for this configuration",
+                "kernel_ms_avg": float(np.mean(march)),
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(line), flush=True)
-
     ctx.close()
-    if world > 1:
-        dist.destroy_process_group()
+    return line
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
+
+    if os.environ.get("VR_BENCH_WATCHDOG"):
+        # rehearsals only: a rank stuck for this many seconds prints its Python stacks and exits
+        import faulthandler
+        log = open(os.environ["VR_BENCH_WATCHDOG_FILE"] + "." + os.environ.get("RANK", "0"), "w") if os.environ.get("VR_BENCH_WATCHDOG_FILE") else sys.stderr
+        faulthandler.dump_traceback_later(float(os.environ["VR_BENCH_WATCHDOG"]), exit=True, file=log)
+
+    su = Setup(args)
+    line = run_sort_last(args, su) if su.cfg["split"] == "sort-last" else run_sort_first(args, su)
+    if su.rank == 0:
+        if su.world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline("c2")
+            line["cpu_baseline_c1"] = cpu_baseline("c1")
+        print(json.dumps(line), flush=True)
+    if su.world > 1:
+        su.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -653,22 +653,52 @@ def test_shading_arguments(vr, ctx, oracle):
         ctx.set_shading(True)
 
 
-def test_bench_with_two_ranks_on_one_gpu(tmp_path):
-    """bench.py's multi-rank control flow (band split, two band buffers in turn, gather, assembly, max over
-    ranks), rehearsed with two ranks on this GPU exchanging over gloo; a small workload."""
+def _run_bench(argv, timeout=240):
+    """`python bench.py ...` as the driver starts it; with --gpus N > 1 it launches its own ranks.  Rehearsal
+    switches: the ranks share this one GPU and exchange over gloo through host memory."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, VR_BENCH_BACKEND="gloo", VR_BENCH_ONE_DEVICE="1", VR_BENCH_WATCHDOG="90")
-    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(29500 + os.getpid() % 2000), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6",
-                          "--warmup", "2", "--volume", "128", "--width", "320", "--height", "200", "--stats-frames", "2"],
-                         capture_output=True, text=True, timeout=120, env=env, cwd=root)
-    assert res.returncode == 0, res.stderr[-2000:]
-    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    env = dict(os.environ, VR_BENCH_BACKEND="gloo", VR_BENCH_ONE_DEVICE="1", VR_BENCH_WATCHDOG="150")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_launches_its_own_ranks_sort_first():
+    """bench.py --gpus 2: band split, two band buffers in turn, gather, assembly, max over ranks; a small workload."""
+    line = _run_bench(["--gpus", "2", "--steps", "6", "--warmup", "2", "--config", "c3", "--volume", "128", "--width", "320", "--height", "200",
+                       "--stats-frames", "2"])
     assert line["n_gpus"] == 2 and line["steps"] == 6 and line["value"] > 0 and line["unit"] == "Gsamples/s"
-    assert "roofline" in line and line["roofline"]["frac"] > 0
+    assert line["scaling"] == "strong" and line["config"]["name"] == "c3" and "overridden" in line["config"]["workload"]
+    assert line["roofline"]["frac"] > 0 and line["roofline"]["bound"] == "hbm"
+
+
+@pytest.mark.parametrize("gpus,schedule", [(8, "binary_swap"), (4, "direct_send")])
+def test_bench_sort_last_configuration(gpus, schedule):
+    """bench.py --config c5: one box per rank, exchange, decision, re-march, gather; per-stage times in the line."""
+    line = _run_bench(["--gpus", str(gpus), "--config", "c5", "--schedule", schedule, "--steps", "3", "--warmup", "1", "--volume", "96",
+                       "--width", "160", "--height", "120", "--stats-frames", "2"])
+    assert line["n_gpus"] == gpus and line["scaling"] == "weak" and line["value"] > 0
+    assert set(line["stages"]) == {"partial_march", "exchange_merge", "decide", "remarch", "gather"}
+    assert len(line["partial_march_ms_per_rank"]) == gpus and line["partial_march_max_over_mean"] >= 1.0
+    assert schedule.replace("_", " ") in line["config"]["workload"]
+
+
+def test_bench_single_gpu_configurations():
+    for name, extra in (("c1", []), ("c2", ["--volume", "128", "--width", "320", "--height", "180"]), ("c5", ["--volume", "96", "--width", "160", "--height", "120"])):
+        line = _run_bench(["--config", name, "--steps", "4", "--warmup", "1", "--stats-frames", "2", "--no-cpu-baseline"] + extra)
+        assert line["n_gpus"] == 1 and line["config"]["name"] == name and line["value"] > 0 and line["ms_per_step"] > 0
+        assert "roofline" in line
+        if name == "c1":
+            assert line["config"]["volume"] == [256, 256, 256] and line["config"]["samples_per_ray"] == 200
+            assert "4 frames" not in line["config"]["workload"] and "fixed camera" in line["config"]["workload"]
+            assert line["roofline"]["frac_whole_frame"] > 0
 
 
 def test_two_frames_in_flight_render_the_same_frames(ctx, oracle, torch):

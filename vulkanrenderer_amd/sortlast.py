@@ -230,19 +230,27 @@ class SortLastFrame:
         assert first == self.first and count == self.span
 
     # -- the frame ------------------------------------------------------------------------------------
-    def render(self):
+    def render(self, mark=None):
         """Renders one frame with the engine's current camera; returns it (uint8 [height, width, 4],
-        on `device`) on rank 0 and None elsewhere."""
+        on `device`) on rank 0 and None elsewhere.  mark(name), if given, is called after each of the
+        five stages has been enqueued (for timing with events on the engine's stream)."""
+        mark = mark or (lambda name: None)
         scope = self.e.scope() if hasattr(self.e, "scope") else _NoScope()
         with scope:
             self.e.render_partial(self.partial)
+            mark("partial_march")
             if self.schedule == "direct_send":
                 self._merge_direct_send()
             else:
                 self._merge_binary_swap()
+            mark("exchange_merge")
             self.e.decide(self.first, self.span, self.merged, self.bytes, self.undecided, self.undecided_count)
+            mark("decide")
             self._remarch()
-            return self._gather()
+            mark("remarch")
+            frame = self._gather()
+            mark("gather")
+            return frame
 
     def _remarch(self):
         if self.solo:
