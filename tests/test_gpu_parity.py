@@ -456,6 +456,144 @@ def test_full_size_volume_all_modes_agree(vr, torch):
         assert np.array_equal(frames[0], frames[2]) and np.array_equal(frames[0], frames[1])
 
 
+def test_reference_data_and_defaults(ctx, vr, tmp_path):
+    """The reference's own data and defaults through the HIP path: a block of its CThead slices (big-endian
+    files, loadVolumeData's format) loaded by vr_load_volume_slices, rendered at its window size 1280x720
+    (main.cpp:30) with samples = 200 (VolumeRendering.comp:173) and both sliders at 0 (main.cpp:69,77), in
+    every mode, for both readings of the sampler's border colour and for the editor's default graphs."""
+    sys_path = os.path.join(cf.GOLDEN)
+    import sys
+    sys.path.insert(0, sys_path)
+    import make_cthead_crop as mk
+    fx = np.load(os.path.join(cf.GOLDEN, "cthead_crop.npz"))
+    mk.write_slices(fx["slices"], str(tmp_path))
+    ctx.load_volume_data(str(tmp_path))
+    info = ctx.volume_info()
+    assert (info["nx"], info["ny"], info["nz"], info["dtype"]) == (88, 88, 113, 2) and info["max_value"] == 3272.0
+    ctx.set_camera(*mk.CAMERA)
+    w, h = mk.SIZE
+    for name, border in mk.BORDERS.items():
+        ctx.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+        ctx.set_sampling(mk.SAMPLES, border)
+        for mode in (0, 2, 1):
+            ctx.set_mode(mode)
+            check_frame(ctx.render(w, h), fx["frame_" + name], "CThead block, %s border, mode %d" % (name, mode))
+    ctx.update_transfer_function(cf.lut_cases()["default_two_points"][0], reset_state=True)
+    ctx.set_sampling(mk.SAMPLES, (0, 0, 0, 0))
+    for mode in (0, 2, 1):
+        ctx.set_mode(mode)
+        got = ctx.render(w, h)
+        assert np.array_equal(got, fx["frame_default_graphs"]) and not got[..., :3].any()
+    # the frame that allocates nothing takes the same path
+    import torch
+    buf = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+    ctx.render_static(w, h, buf.data_ptr())
+    ctx.synchronize()
+    assert np.array_equal(buf.cpu().numpy(), fx["frame_transparent"])
+
+
+def silhouette_rects(frame, size=128, count=4):
+    """Rectangles of size x size pixels centred on the object's outline in a rendered frame: where a row or
+    a column of the frame goes from background to object."""
+    h, w = frame.shape[:2]
+    lit = frame[..., :3].any(axis=-1)
+    rects = []
+
+    def add(cx, cy):
+        x0 = int(min(max(cx - size // 2, 0), w - size)) & ~7
+        y0 = int(min(max(cy - size // 2, 0), h - size)) & ~7
+        rects.append((x0, y0, x0 + size, y0 + size))
+    for frac in np.linspace(0.3, 0.7, count // 2):
+        row = int(h * frac)
+        cols = np.flatnonzero(lit[row])
+        if cols.size:
+            add(cols[0], row)
+            add(cols[-1], row)
+    col = w // 2
+    rows = np.flatnonzero(lit[:, col])
+    if rows.size:
+        add(col, rows[0])
+        add(col, rows[-1])
+    return rects
+
+
+def test_full_size_volume_silhouette_and_whole_frames(vr, torch):
+    """The headline size where it is hard: 2048^3 uint16 at 3840x2160, three cameras of the orbit.  Whole frames
+    of the fast march against the skipping reference-order march (all 8.3 M pixels), and rectangles on the
+    object's outline against the literal shader loop; the fast march must have used its hand-over and its
+    replay on them."""
+    n, w, h = 2048, 3840, 2160
+    samples = int(math.ceil(2 * math.sqrt(3) * n)) - 1
+    with vr.VolumeRenderer(0) as c:
+        raw = torch.empty(n ** 3, dtype=torch.int16, device="cuda")
+        torch.cuda.synchronize()
+        c.phantom_generate_device(raw.data_ptr(), 2, n)
+        c.upload_volume_device(raw.data_ptr(), 2, n, n, n)
+        c.synchronize()
+        del raw
+        torch.cuda.empty_cache()
+        c.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+        c.set_sampling(samples)
+        for deg in (-180.0, -75.0, 70.0):
+            c.set_camera(math.radians(deg), math.radians(20.0))
+            c.set_mode(1)
+            fast, st = c.render(w, h, stats=True)
+            assert st["long_rays"] > 0 and st["replay_rays"] > 0 and st["long_samples"] > 0
+            c.set_mode(2)
+            skip = c.render(w, h)
+            assert np.array_equal(fast, skip), (deg, cf.frame_report(fast, skip))
+            rects = silhouette_rects(fast)
+            assert len(rects) >= 3
+            handed = replayed = 0
+            for rect in rects:
+                x0, y0, x1, y1 = rect
+                crop = fast[y0:y1, x0:x1]
+                assert crop[..., :3].any() and not crop[..., :3].any(axis=-1).all(), rect     # object and background
+                c.set_mode(0)
+                literal = c.render(w, h, rect=rect)
+                assert np.array_equal(literal, crop), (deg, rect, cf.frame_report(literal, crop))
+                c.set_mode(1)
+                again, rs = c.render(w, h, stats=True, rect=rect)
+                assert np.array_equal(again, crop), (deg, rect)
+                handed += rs["long_rays"]
+                replayed += rs["replay_rays"]
+            print("camera %.0f: %d rectangles on the outline, %d rays handed over, %d replayed" % (deg, len(rects), handed, replayed))
+            assert handed > 0 and replayed > 0
+
+
+def test_config3_bands_reassemble(vr, torch):
+    """BASELINE configs[2]: 1024^3 uint16 at 3840x2160, sort-first.  The bands of 2, 4 and 8 parts (fast march)
+    put together give the frame the skipping reference-order march renders in one piece, and rectangles on the
+    outline equal the literal shader loop."""
+    n, w, h = 1024, 3840, 2160
+    samples = int(math.ceil(2 * math.sqrt(3) * n)) - 1
+    with vr.VolumeRenderer(0) as c:
+        raw = torch.empty(n ** 3, dtype=torch.int16, device="cuda")
+        torch.cuda.synchronize()
+        c.phantom_generate_device(raw.data_ptr(), 2, n)
+        c.upload_volume_device(raw.data_ptr(), 2, n, n, n)
+        c.synchronize()
+        del raw
+        c.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+        c.set_sampling(samples)
+        c.set_camera(math.radians(-140.0), math.radians(20.0))
+        c.set_mode(2)
+        whole = c.render(w, h)
+        assert whole[..., :3].any()
+        c.set_mode(0)
+        for rect in silhouette_rects(whole, size=96):
+            x0, y0, x1, y1 = rect
+            assert np.array_equal(c.render(w, h, rect=rect), whole[y0:y1, x0:x1]), rect
+        c.set_mode(1)
+        for parts in (2, 4, 8):
+            got = np.zeros_like(whole)
+            for part in range(parts):
+                got[vr.band_row_indices(h, part, parts)] = c.render_bands(w, h, part, parts)
+            assert np.array_equal(got, whole), (parts, cf.frame_report(got, whole))
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_sort_first_bands_tile_the_frame(ctx, vr, oracle, mode):
     w, h = 70, 53                                   # ragged: last band has 5 rows, last tile column 6 pixels

@@ -213,3 +213,19 @@ def test_reference_dataset_frame_matches_golden(oracle):
     vol, _ = oracle.load_slices(make_cthead.DATA)
     want = np.load(os.path.join(cf.GOLDEN, "cthead_frame.npz"))["frame"]
     assert np.array_equal(make_cthead.render(vol), want)
+
+
+def test_cthead_block_frames_match_golden(oracle, tmp_path):
+    """The committed block of the reference's CThead slices through the checker's slice loader, at the
+    reference's window size, sample count and default camera: the frames in cthead_crop.npz."""
+    sys.path.insert(0, cf.GOLDEN)
+    import make_cthead_crop as mk
+    fx = np.load(os.path.join(cf.GOLDEN, "cthead_crop.npz"))
+    assert fx["slices"].dtype == np.dtype(">u2") and fx["slices"].shape == (113, 88, 88)
+    mk.write_slices(fx["slices"], str(tmp_path))
+    frames, shape, mx = mk.frames_of(str(tmp_path))
+    assert shape == (113, 88, 88) and mx == float(fx["max_value"]) == 3272.0
+    for name, frame in frames.items():
+        assert np.array_equal(frame, fx[name]), name
+    assert not fx["frame_default_graphs"][..., :3].any() and fx["frame_transparent"][..., :3].any()
+    assert not np.array_equal(fx["frame_transparent"], fx["frame_opaque"])
