@@ -67,9 +67,15 @@ print("per wave: rounds mean %.1f p90 %.0f max %.0f | max-lane model iters mean 
 busy = rounds > 0
 print("waves with rounds:", int(busy.sum()), "their dur mean %.1f us, rounds mean %.1f, both mean %.1f" % (dur[busy].mean(), rounds[busy].mean(), mboth[busy].mean()))
 print("waves without rounds: dur mean %.1f us, both mean %.1f" % (dur[~busy].mean(), mboth[~busy].mean()))
-hw = t[:, 2]
-xcc = hw >> 32
-print("waves per XCC", np.bincount(xcc.astype(np.int64), minlength=8))
+wave_passes = (t[:, 2] & 0xffffffff).astype(np.float64)
+lane_passes = (t[:, 2] >> 32).astype(np.float64)
+print("passes of the skipping loop the WAVE executed: mean %.1f (busy waves %.1f, p90 %.0f); lanes active in a pass: %.1f of 64" % (
+    wave_passes.mean(), wave_passes[busy].mean(), np.percentile(wave_passes[busy], 90), lane_passes.sum() / max(1.0, wave_passes.sum())))
+for lo, hi in ((1, 8), (8, 16), (16, 32), (32, 64), (64, 128), (128, 1e9)):
+    sel = busy & (rounds >= lo) & (rounds < hi)
+    if sel.any():
+        print("busy waves with %3.0f..%-4.0f rounds: %6d, wave passes mean %.1f, max-lane passes %.1f, lane use in rounds %.2f, wave-time share %.3f" % (
+            lo, hi, sel.sum(), wave_passes[sel].mean(), mboth[sel].mean(), ssum[sel].sum() / (rounds[sel] * 64).sum(), dur[sel].sum() / dur.sum()))
 # total work by duration: sum of durations vs span*slots
 print("sum dur (wave-us)", dur.sum(), "-> avg resident waves", dur.sum() / t1.max())
 # the longest waves: where are they in the image

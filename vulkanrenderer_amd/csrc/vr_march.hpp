@@ -977,7 +977,7 @@ constexpr int kDecideEvery = VR_DECIDE_EVERY;   // a power of two
 #endif
 constexpr bool kMaterialBet = VR_MATERIAL_BET;
 #ifndef VR_CLEAR_RUN
-#define VR_CLEAR_RUN 8
+#define VR_CLEAR_RUN 12
 #endif
 constexpr int kClearRun = VR_CLEAR_RUN;   // transparent taps in a row that end the bet on material
 #ifndef VR_MODEL_CELLS
@@ -1056,7 +1056,7 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
 {
 #ifdef VR_DIAG
     const unsigned long long diag_t0 = wall_clock64();
-    unsigned int diag_model = 0, diag_exact = 0, diag_rounds = 0, diag_sampled = 0;
+    unsigned int diag_model = 0, diag_exact = 0, diag_rounds = 0, diag_sampled = 0, diag_wave_passes = 0;
     long long diag_c0 = clock64(), diag_setup = 0, diag_skip = 0, diag_sample = 0;
 #endif
     const Ray r = make_ray(fp, in_rect ? px : fp.x0, in_rect ? py : fp.y0);
@@ -1151,6 +1151,9 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
         while (marching && !have && work < budget) {
             if (t < t_stop) { marching = false; break; }
             work++;
+#ifdef VR_DIAG
+            if ((int)(threadIdx.x & 63) == __builtin_ctzll(__ballot(true))) diag_wave_passes++;   // one lane counts for the wave
+#endif
             // position of tap t in the padded texel grid for the span counts below: the line model's, or,
             // when every pass takes the exact position anyway, that one (it differs from the model by
             // rounding only, which the margin covers just the same, and the model's six coefficients
@@ -1229,6 +1232,10 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
             } else {
                 have = true;
                 taps = 1;
+                // a block that is not transparent: bet on the taps behind this one as well (at a surface the
+                // first of them are still air; each used to cost a pass of this loop and a fetch)
+                material = kMaterialBet;
+                clear_run = 0;
                 continue;
             }
             const int n = span_inside(gx, gy, gz, lox, loy, loz, extent, rm);
@@ -1354,8 +1361,10 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
     }
 #ifdef VR_DIAG
     // diagnostic build only: wave start/end wall clock (100 MHz) and placement, one record per wave
-    unsigned int diag_both = diag_model + diag_exact, diag_sum = diag_sampled;
+    unsigned int diag_both = diag_model + diag_exact, diag_sum = diag_sampled, diag_lane_passes = diag_model + diag_exact;
     for (int o = 32; o > 0; o >>= 1) {
+        diag_wave_passes += (unsigned int)__shfl_xor((int)diag_wave_passes, o);
+        diag_lane_passes += (unsigned int)__shfl_xor((int)diag_lane_passes, o);
         diag_model = max(diag_model, (unsigned int)__shfl_xor((int)diag_model, o));
         diag_exact = max(diag_exact, (unsigned int)__shfl_xor((int)diag_exact, o));
         diag_both = max(diag_both, (unsigned int)__shfl_xor((int)diag_both, o));
@@ -1373,7 +1382,8 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
         g_vr_timeline[wave_id * 8 + 7] = (unsigned long long)(clock64() - diag_c0);
         g_vr_timeline[wave_id * 8 + 0] = diag_t0;
         g_vr_timeline[wave_id * 8 + 1] = wall_clock64();
-        g_vr_timeline[wave_id * 8 + 2] = ((unsigned long long)xcc << 32) | hw;
+        (void)hw; (void)xcc;
+        g_vr_timeline[wave_id * 8 + 2] = (unsigned long long)diag_wave_passes | ((unsigned long long)diag_lane_passes << 32);
         g_vr_timeline[wave_id * 8 + 3] = (unsigned long long)diag_rounds | ((unsigned long long)diag_model << 12) |
                                          ((unsigned long long)diag_exact << 24) | ((unsigned long long)diag_both << 36) |
                                          ((unsigned long long)diag_sum << 48);
