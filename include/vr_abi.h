@@ -209,6 +209,7 @@ int vr_march_kernel_times(vr_ctx *ctx, float *ms, int capacity, int *count);
  * the sort-first share part/parts of it) a few times for each candidate of the per-lane work budget
  * -- how long a lane marches its ray before a whole wave takes it over -- and keeps the fastest.
  * Frames are identical for every value; only the time changes with volume, table and image size.
+ * Without this call the budget follows the size of the launch (small frames hand rays over early).
  * chosen_budget may be NULL.  No counterpart in the reference. */
 int vr_tune(vr_ctx *ctx, int width, int height, int part, int parts, int *chosen_budget);
 

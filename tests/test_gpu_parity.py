@@ -623,11 +623,12 @@ def test_tune_keeps_the_frame(ctx, oracle):
     ctx.set_sampling(250)
     ctx.set_mode(0)
     ref = ctx.render(160, 120)
-    assert ctx.tune(160, 120) in (64, 80, 96, 112, 128)
+    candidates = (8, 16, 32, 48, 64, 96, 128, 160)
+    assert ctx.tune(160, 120) in candidates
     assert np.array_equal(ctx.render(160, 120), ref)          # tune leaves mode and pipeline as they were
     ctx.set_mode(1)
     assert np.array_equal(ctx.render(160, 120), ref)
-    assert ctx.tune(160, 120, 1, 3) in (64, 80, 96, 112, 128)
+    assert ctx.tune(160, 120, 1, 3) in candidates
     assert np.array_equal(ctx.render(160, 120), ref)
     # a part that owns no band (more parts than bands) has nothing to measure: the budget stays
     kept = ctx.tune(160, 120, 1, 3)

@@ -69,7 +69,8 @@ struct vr_ctx {
     int waves_per_block = 1;
     // memory round trips (fetch rounds + passes of the skipping loop) a lane spends on a ray before a
     // wave takes the ray over
-    int lane_budget = vr::kLaneBudget;
+    // 0: by the size of the launch (lane_budget_for); set by vr_tune or VR_LANE_BUDGET otherwise
+    int lane_budget = 0;
     // The same for the sort-last lane march.  Boxes cannot stop a ray as early as the whole-volume march
     // (they do not know what lies in front), so their rays need more taps.
     int partial_budget = 96;
@@ -92,6 +93,7 @@ struct vr_ctx {
     bool shading = false;
     float scene[4] = {1.0f, 1.0f, 1.0f, 100.0f};   // main.cpp:90-98
     int pipeline_depth = 1;
+    int long_group = 0;       // lanes per handed-over ray in k_march_long: 0 = by frame size, else 32 or 64 (VR_LONG_GROUP)
     int tail_blocks = 8192;   // grid of the wave-per-ray kernels: more, shorter queues per wave even out the rays' lengths (VR_TAIL_BLOCKS)
     hipStream_t tail_stream = nullptr;
     hipEvent_t main_done[2] = {nullptr, nullptr}, tail_done[2] = {nullptr, nullptr}, frame_done = nullptr;
@@ -410,13 +412,27 @@ struct FrameBuffers {
     hipEvent_t main_done;    // recorded after the lane march when the tail runs on another stream, else null
 };
 
+// The lane budget when neither vr_tune nor the environment has set one.  The lane march is one wave per
+// 8x8 tile.  A 4K frame gives each SIMD over a hundred waves in turn and long lane marches keep its
+// vector pipes busy; a small frame (or a rank's share of a sort-first split) has a few waves per SIMD,
+// the march is then a chain of dependent memory round trips, and handing rays over early lets the
+// wave-per-ray kernel, which takes 64 to 128 taps per round trip, finish them side by side.  Measured
+// on MI355X: 512x512 32 (0.19 ms per frame against 0.47 with 128), 1080p 64, 4K 128.
+int lane_budget_for(const vr_ctx *ctx, int tile_waves)
+{
+    if (ctx->lane_budget > 0) return ctx->lane_budget;
+    if (tile_waves < 8192) return 32;
+    if (tile_waves < 65536) return 64;
+    return vr::kLaneBudget;
+}
+
 template <typename T, bool STATS, bool SHADE>
 void launch_frame_as(vr_ctx *ctx, const vr::FrameParams &fp, uint32_t *d_out, const FrameBuffers &fb)
 {
     // one wave per 8x8 tile; a band of 16 rows is two tile rows
-    const int tiles = ((fp.x1 - fp.x0 + 7) / 8) * 2 * bands_of_part(fp.y1 - fp.y0, fp.part, fp.parts);
+    const int tile_waves = ((fp.x1 - fp.x0 + 7) / 8) * 2 * bands_of_part(fp.y1 - fp.y0, fp.part, fp.parts);
     const int waves_per_block = ctx->waves_per_block;
-    const dim3 grid((unsigned)((tiles + waves_per_block - 1) / waves_per_block)), block(64 * waves_per_block);
+    const dim3 grid((unsigned)((tile_waves + waves_per_block - 1) / waves_per_block)), block(64 * waves_per_block);
     const vr::VolumeView vol = view_of(ctx);
     const float4 border = make_float4(ctx->border[0], ctx->border[1], ctx->border[2], ctx->border[3]);
     const float4 *lut = reinterpret_cast<const float4 *>(ctx->lut);
@@ -444,7 +460,7 @@ void launch_frame_as(vr_ctx *ctx, const vr::FrameParams &fp, uint32_t *d_out, co
             (void)hipEventRecord(ctx->ring_a[slot], s);   // the ring times the march kernel alone
         }
         const dim3 replay_grid((unsigned)ctx->tail_blocks);  // 4 waves each, one ray per wave and pass
-        hipLaunchKernelGGL((vr::k_march_fast<T, STATS, SHADE>), grid, block, 0, s, vol, fp, lut, border, ctx->lut_info, d_out, fb.counters, ctx->touched, fb.queue, fb.long_queue, ctx->lane_budget, tiles, tiles_x);
+        hipLaunchKernelGGL((vr::k_march_fast<T, STATS, SHADE>), grid, block, 0, s, vol, fp, lut, border, ctx->lut_info, d_out, fb.counters, ctx->touched, fb.queue, fb.long_queue, lane_budget_for(ctx, tile_waves), tiles, tiles_x);
         (void)hipEventRecord(ctx->ring_b[slot], s);
         if (STATS)
             hipLaunchKernelGGL(vr::k_count_bits, dim3(1024), dim3(256), 0, s, ctx->touched, (ctx->brick_count + 31) / 32, &fb.counters->main_bricks);
@@ -453,7 +469,13 @@ void launch_frame_as(vr_ctx *ctx, const vr::FrameParams &fp, uint32_t *d_out, co
             (void)hipEventRecord(fb.main_done, s);
             (void)hipStreamWaitEvent(ts, fb.main_done, 0);
         }
-        hipLaunchKernelGGL((vr::k_march_long<T, STATS, SHADE>), replay_grid, dim3(256), 0, ts, vol, fp, lut, border, ctx->lut_info, d_out, fb.counters, ctx->touched, fb.queue, fb.long_queue);
+        // a whole wave per handed-over ray for large frames (long rays of large volumes), two rays per wave for
+        // small ones, where most rays are handed over with few taps left (VR_LONG_GROUP=32|64 overrides)
+        const bool two_per_wave = ctx->long_group ? ctx->long_group == 32 : tile_waves < 65536;
+        if (two_per_wave)
+            hipLaunchKernelGGL((vr::k_march_long<T, 32, STATS, SHADE>), replay_grid, dim3(256), 0, ts, vol, fp, lut, border, ctx->lut_info, d_out, fb.counters, ctx->touched, fb.queue, fb.long_queue);
+        else
+            hipLaunchKernelGGL((vr::k_march_long<T, 64, STATS, SHADE>), replay_grid, dim3(256), 0, ts, vol, fp, lut, border, ctx->lut_info, d_out, fb.counters, ctx->touched, fb.queue, fb.long_queue);
         hipLaunchKernelGGL((vr::k_replay_exact<T, STATS, SHADE>), replay_grid, dim3(256), 0, ts, vol, fp, lut, border, ctx->lut_info, d_out, fb.counters, ctx->touched, fb.queue, tiles, tiles_x);
     }
 }
@@ -499,6 +521,7 @@ int vr_create(int device, vr_ctx **out)
     if (const char *e = std::getenv("VR_TILE_CLIP")) ctx->tile_clip = std::atoi(e) != 0;
     if (const char *e = std::getenv("VR_LANE_BUDGET")) ctx->lane_budget = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("VR_PARTIAL_BUDGET")) ctx->partial_budget = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("VR_LONG_GROUP")) ctx->long_group = std::atoi(e) == 32 ? 32 : (std::atoi(e) == 64 ? 64 : 0);
     if (const char *e = std::getenv("VR_TAIL_BLOCKS")) ctx->tail_blocks = std::max(64, std::min(65536, std::atoi(e))) & ~31;   // a multiple of 32: for_queue_entries
     if (const char *e = std::getenv("VR_WAVES_PER_BLOCK")) ctx->waves_per_block = std::max(1, std::min(4, std::atoi(e)));
     if (device < static_scratch::kMaxDevices && !g_scratch_ptr[device]) {
@@ -1140,7 +1163,7 @@ int vr_tune(vr_ctx *ctx, int width, int height, int part, int parts, int *chosen
     if (parts < 1 || part < 0 || part >= parts) return fail(ctx, VR_ERR_ARG, "bad part");
     if (width < 2 || height < 2 || width > 65536 || height > 65536) return fail(ctx, VR_ERR_ARG, "image size out of range");
     if (rows_of_part(height, part, parts) == 0) {   // more parts than bands: this part renders nothing, nothing to measure
-        if (chosen_budget) *chosen_budget = ctx->lane_budget;
+        if (chosen_budget) *chosen_budget = lane_budget_for(ctx, 0);
         return VR_OK;
     }
     if (int rc = bind(ctx)) return rc;
@@ -1152,8 +1175,8 @@ int vr_tune(vr_ctx *ctx, int width, int height, int part, int parts, int *chosen
     ctx->pipeline_depth = 1;
     // How long a lane stays with its ray before it hands it to a wave of its own: the best value
     // depends on how the rays' lengths are spread, i.e. on volume, table, image size and share.
-    const int candidates[] = {64, 80, 96, 112, 128};
-    int best = before, rc = VR_OK;
+    const int candidates[] = {8, 16, 32, 48, 64, 96, 128, 160};
+    int best = before > 0 ? before : vr::kLaneBudget, rc = VR_OK;
     float best_ms = 3.0e38f;
     for (int budget : candidates) {
         ctx->lane_budget = budget;

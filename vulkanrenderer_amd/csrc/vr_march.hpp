@@ -1437,19 +1437,37 @@ constexpr int kSerialFoldMax = VR_SERIAL_FOLD_MAX;    // up to this many lanes' 
 #endif
 constexpr int kLongTaps = VR_LONG_TAPS;   // consecutive taps per lane and round in the wave-per-ray march
 
-// Continuation of a ray k_march_fast ran out of budget on, by a whole wave.  The 64 lanes fetch 64
-// consecutive taps at once (or the whole wave steps over an empty cube), then the taps with a
-// non-zero alpha are blended front to back in tap order, the accumulation k_march_fast does one tap
-// at a time; the decision test runs once per 64 taps.  Returns whether the bytes are decided.
+// Lanes that march one handed-over ray together (template parameter G of the wave-per-ray kernels): a whole
+// wave, or half a wave so that a wave carries two rays at a time.  The march is a chain of dependent
+// memory round trips; two rays in a wave share its instructions and its slot on the SIMD, which pays
+// when there are many rays with few taps left each (small frames, where most rays are handed over early);
+// a whole wave covers 128 taps per round trip, which pays for the long rays of large volumes.
+// Continuation of a ray k_march_fast ran out of budget on, by a group of G lanes.  All control
+// flow below is uniform within a group (the two groups of a wave may diverge); every shuffle and ballot
+// stays inside the group.  The lanes fetch G * kLongTaps consecutive taps at once, then the taps
+// with a non-zero alpha are blended front to back in tap order, the accumulation k_march_fast does one
+// tap at a time; the decision test runs once per round.  While the ray is inside material a round is a
+// single memory round trip: the block masks of a round's taps are requested one round ahead, together
+// with the voxels of the round before, so the voxels of the taps that matter can be requested as soon
+// as the round starts.  After a round without any tap that matters the group walks on through the
+// occupancy pyramid, a cube at a time.  `valid`: the group has a ray at all.
+// Returns whether the bytes are decided.
 // With PARTIAL (sort-last) only the taps of this context's box are taken, nothing is decided, the
 // march stops once the box's own taps have made the ray dark, and the sums go to partial_out.
-template <typename T, bool STATS, bool PARTIAL = false, bool SHADE = false>
+template <typename T, int G, bool STATS, bool PARTIAL = false, bool SHADE = false>
 __device__ __forceinline__ bool continue_ray(const VolumeView &vol, const FrameParams &fp, const float4 *s_lut,
-                                             const Decider &dec, Counters *ctr, uint32_t *touched, const LongRay &e,
+                                             const Decider &dec, Counters *ctr, uint32_t *touched, const LongRay &e, bool valid,
                                              uint32_t &rgba, float *__restrict__ partial_out = nullptr)
 {
+    static_assert(G == 16 || G == 32 || G == 64, "a group is a wave, a half or a quarter of one");
     const int lane = threadIdx.x & 63;
-    // the ray and its clipped tap range as the lane march left them (identical in every lane)
+    const int sub = lane & (G - 1);          // lane within the group
+    const int gbase = lane & ~(G - 1);       // first lane of the group
+    auto group_ballot = [&](bool flag) -> unsigned long long {
+        const unsigned long long m = __ballot(flag);
+        return G == 64 ? m : ((m >> gbase) & ((1ull << (G & 63)) - 1ull));
+    };
+    // the ray and its clipped tap range as the lane march left them (identical in every lane of the group)
     Ray r;
     r.o[0] = fp.loc[0]; r.o[1] = fp.loc[1]; r.o[2] = fp.loc[2];
     r.d[0] = e.d[0]; r.d[1] = e.d[1]; r.d[2] = e.d[2];
@@ -1465,67 +1483,103 @@ __device__ __forceinline__ bool continue_ray(const VolumeView &vol, const FrameP
     bool decided = false;
     rgba = 0xff000000u;
     unsigned long long evaluated = 0;
-    while (t >= rm.t_stop && !decided && !(PARTIAL && Tr < kTrCut)) {
-        const int n = empty_span(vol, rm, t);   // wave-uniform
-        if (n > 0) {
-            t -= n;
-            continue;
-        }
-        // lane l takes the kLongTaps consecutive taps t - l * kLongTaps - k; their loads are in flight together
-        Cell cs[kLongTaps];
-        uint32_t bricks[kLongTaps];
-        bool fetch[kLongTaps];
+    // the back-most tap is needed when the march ends undecided: requested together with the last round's taps
+    const Tap back_p = tap_position(r, vol, step, 0);
+    const Cell back_c = tap_cell(back_p, vol);
+    const uint32_t back_brick = brick_of(back_c, vol);
+    TapWords back_raw{};
+    bool back_requested = false;
+    // One round's taps of a lane: cell, brick, whether the tap exists (and is this box's), and the brick's
+    // block mask, which is requested a round ahead so that it has arrived when the round starts.
+    struct Slot {
+        Cell c;
+        uint32_t brick;
+        bool fetch;
+        unsigned long long mask;
+    };
+    auto prepare = [&](int t0, Slot *slot) {
 #pragma unroll
         for (int k = 0; k < kLongTaps; k++) {
-            const int tt = t - (lane * kLongTaps + k);
-            fetch[k] = tt >= rm.t_stop;
+            const int tt = t0 - (sub * kLongTaps + k);
+            slot[k].fetch = valid && tt >= rm.t_stop;
             if (PARTIAL) {
-                if (!tap_cell_local(tap_position(r, vol, step, fetch[k] ? tt : rm.t_stop), vol, cs[k])) fetch[k] = false;
-                if (!fetch[k]) cs[k].sx = cs[k].sy = cs[k].sz = 0;   // any cell of the box: never fetched
+                if (!tap_cell_local(tap_position(r, vol, step, slot[k].fetch ? tt : rm.t_stop), vol, slot[k].c)) slot[k].fetch = false;
+                if (!slot[k].fetch) slot[k].c.sx = slot[k].c.sy = slot[k].c.sz = 0;   // any cell of the box: never used
             } else {
-                cs[k] = tap_cell(tap_position(r, vol, step, fetch[k] ? tt : rm.t_stop), vol);
+                slot[k].c = tap_cell(tap_position(r, vol, step, slot[k].fetch ? tt : rm.t_stop), vol);
             }
-            bricks[k] = brick_of(cs[k], vol);
+            slot[k].brick = brick_of(slot[k].c, vol);
+            slot[k].mask = ~0ull;
+            if (slot[k].fetch) slot[k].mask = vol.micro[slot[k].brick];   // all ones for a brick the pyramid calls empty
         }
-#pragma unroll
-        for (int k = 0; k < kLongTaps; k++)
-            if (fetch[k] && (brick_empty(bricks[k], vol) || micro_empty(vol.micro[bricks[k]], cs[k]))) fetch[k] = false;
+    };
+    Slot cur[kLongTaps], nxt[kLongTaps];
+    int cur_t = t;
+    prepare(t, cur);
+    bool spec = true;   // the hand-over happens inside material: expect the next taps to matter
+    while (valid && t >= rm.t_stop && !decided && !(PARTIAL && Tr < kTrCut)) {
+        if (!spec) {
+            const int n = empty_span(vol, rm, t);   // group-uniform
+            if (n > 0) {
+                t -= n;
+                continue;
+            }
+        }
+        if (cur_t != t) {      // the group has jumped: the masks requested ahead were for other taps
+            prepare(t, cur);
+            cur_t = t;
+        }
+        // lane l takes the kLongTaps consecutive taps t - l * kLongTaps - k; the voxels of those whose block is
+        // not transparent and the masks of the next round's taps are requested together
         TapWords raw[kLongTaps];
+        bool need[kLongTaps];
 #pragma unroll
-        for (int k = 0; k < kLongTaps; k++)
-            if (fetch[k]) raw[k] = fetch_volume<T>(cs[k], bricks[k], vol);
+        for (int k = 0; k < kLongTaps; k++) {
+            need[k] = cur[k].fetch && !micro_empty(cur[k].mask, cur[k].c);
+            if (need[k]) raw[k] = fetch_volume<T>(cur[k].c, cur[k].brick, vol);
+        }
+        const int t_next = t - G * kLongTaps;
+        if (!PARTIAL && !back_requested && t_next < rm.t_stop) {
+            back_raw = fetch_volume<T>(back_c, back_brick, vol);
+            back_requested = true;
+        }
+        prepare(t_next, nxt);
         Blend v{0.0, 0.0, 0.0, 1.0, 0.0f};
 #pragma unroll
         for (int k = 0; k < kLongTaps; k++) {
-            if (!fetch[k]) continue;
-            float4 tf = sample_tf(s_lut, filter_volume<T>(raw[k], cs[k], vol));
+            if (!need[k]) continue;
+            float4 tf = sample_tf(s_lut, filter_volume<T>(raw[k], cur[k].c, vol));
             if (STATS) {
                 evaluated++;
-                atomicOr(&touched[bricks[k] >> 5], 1u << (bricks[k] & 31));
+                atomicOr(&touched[cur[k].brick >> 5], 1u << (cur[k].brick & 31));
             }
             if (SHADE && tf.w != 0.0f) {
-                const float sh = shade_tap<T, STATS>(vol, fp, r, step, t - (lane * kLongTaps + k), touched, evaluated);
+                const float sh = shade_tap<T, STATS>(vol, fp, r, step, t - (sub * kLongTaps + k), touched, evaluated);
                 tf.x += sh; tf.y += sh; tf.z += sh;
             }
             if (tf.w != 0.0f) blend_under(v, blend_of_tap(true, tf));
         }
-        unsigned long long todo = __ballot(v.s != 0.0f);
+        bool mattered = false;
+#pragma unroll
+        for (int k = 0; k < kLongTaps; k++) mattered = mattered || need[k];
+        spec = group_ballot(mattered) != 0ull;
+        unsigned long long todo = group_ballot(v.s != 0.0f);
         if (__popcll(todo) > kSerialFoldMax) {
-            // many taps to blend: "front over back" is associative, so the 64 lanes reduce in six
-            // shuffle steps instead of one lane at a time (lane 0 holds the front-most taps)
-            for (int o = 1; o < 64; o <<= 1) {
+            // many taps to blend: "front over back" is associative, so the lanes reduce in log2(G)
+            // shuffle steps instead of one lane at a time (lane 0 of the group holds the front-most taps)
+            for (int o = 1; o < G; o <<= 1) {
                 Blend back;
-                back.f0 = __shfl_down(v.f0, o);
-                back.f1 = __shfl_down(v.f1, o);
-                back.f2 = __shfl_down(v.f2, o);
-                back.tr = __shfl_down(v.tr, o);
-                back.s = __shfl_down(v.s, o);
-                blend_under(v, back);   // lanes whose partner lies beyond the wave never feed lane 0
+                back.f0 = __shfl_down(v.f0, o, G);
+                back.f1 = __shfl_down(v.f1, o, G);
+                back.f2 = __shfl_down(v.f2, o, G);
+                back.tr = __shfl_down(v.tr, o, G);
+                back.s = __shfl_down(v.s, o, G);
+                blend_under(v, back);   // lanes whose partner lies beyond the group never feed its lane 0
             }
             todo = 1ull;
         }
         while (todo) {
-            const int src = __builtin_ctzll(todo);   // lowest lane = front-most taps of the chunk
+            const int src = gbase + __builtin_ctzll(todo);   // lowest lane = front-most taps of the chunk
             todo &= todo - 1;
             Blend part;
             part.f0 = __shfl(v.f0, src);
@@ -1539,68 +1593,72 @@ __device__ __forceinline__ bool continue_ray(const VolumeView &vol, const FrameP
             S += (float)Tr * part.s * 1.000001f;
             Tr = Tr * part.tr;
         }
-        t -= 64 * kLongTaps;
+        t = t_next;
+#pragma unroll
+        for (int k = 0; k < kLongTaps; k++) cur[k] = nxt[k];
+        cur_t = t;
         if (!PARTIAL && dec.ok && Tr < (double)dec.tr_gate) decided = dec.decide(F0, F1, F2, Tr, S, (t > 0 ? t : 0) + 1, rgba);
     }
     if (PARTIAL) {
         float res[kPartial];
         finish_partial<T>(vol, r, step, s_lut, F0, F1, F2, Tr, S, res);
-        if (lane == 0) {
+        if (valid && sub == 0) {
             float *o = partial_out + (size_t)e.pixel_id * kPartial;
             for (int k = 0; k < kPartial; k++) o[k] = res[k];
         }
         return false;
     }
-    if (!decided) {
+    if (valid && !decided) {
         // back-most tap: its colour enters unweighted by its alpha (VolumeRendering.comp:189-191)
-        const Tap p = tap_position(r, vol, step, 0);
-        const Cell c = tap_cell(p, vol);
-        const uint32_t brick = brick_of(c, vol);
-        const float4 tf = sample_tf(s_lut, sample_volume<T>(c, brick, vol));
-        if (STATS && lane == 0) {
+        if (!back_requested) back_raw = fetch_volume<T>(back_c, back_brick, vol);
+        const float4 tf = sample_tf(s_lut, filter_volume<T>(back_raw, back_c, vol));
+        if (STATS && sub == 0) {
             evaluated++;
-            atomicOr(&touched[brick >> 5], 1u << (brick & 31));
+            atomicOr(&touched[back_brick >> 5], 1u << (back_brick & 31));
         }
         F0 = __builtin_fma(Tr, (double)tf.x, F0);
         F1 = __builtin_fma(Tr, (double)tf.y, F1);
         F2 = __builtin_fma(Tr, (double)tf.z, F2);
         decided = dec.ok && dec.decide(F0, F1, F2, 0.0, S, 0, rgba);
     }
-    if (STATS) {
+    if (STATS && valid) {
         atomicAdd(&ctr->samples_evaluated, evaluated);
         atomicAdd(&ctr->long_samples, evaluated);
-        for (int o = 32; o > 0; o >>= 1) evaluated += __shfl_xor(evaluated, o);
-        if (lane == 0) atomicAdd(&ctr->hist_long[63 - __builtin_clzll(evaluated + 1ull)], 1u);
+        for (int o = G / 2; o > 0; o >>= 1) evaluated += __shfl_xor(evaluated, o);
+        if (sub == 0) atomicAdd(&ctr->hist_long[63 - __builtin_clzll(evaluated + 1ull)], 1u);
     }
     return decided;
 }
 
-// Which entries of a hand-over queue a wave of a wave-per-ray kernel takes.  The lane march appends
-// the rays of a wave (one 8x8 pixel tile) in one piece, so neighbours in the queue are neighbours on
-// the screen and walk the same bricks.  Workgroups are dealt round-robin to the chip's eight XCDs,
-// each with an L2 of its own (blocks b and b + 8 share one): were consecutive entries handed to
-// consecutive blocks, every XCD would fetch every tile's bricks from memory for itself.  Instead a run of
-// consecutive entries stays on one XCD: four blocks of that XCD take a quarter of the run each, and the
-// four waves of a block work on four neighbouring entries at any time.  A wave takes up to four entries
-// of a run in turn (one when the queue is short enough for every entry to have a wave of its own).
-// Calls f(entry) for each entry of this wave; the waves of the grid together cover [0, entries) once.
-// Correct for any placement of the blocks, only the cache hit rate depends on it.  gridDim.x must be a
-// multiple of 32.
-template <typename F>
+// Which entries of a hand-over queue the groups of a wave-per-ray kernel take (GROUPS groups of
+// 64 / GROUPS lanes per wave, one ray each).  The lane march appends the rays of a wave (one 8x8 pixel
+// tile) in one piece, so neighbours in the queue are neighbours on the screen and walk the same bricks.
+// Workgroups are dealt round-robin to the chip's eight XCDs, each with an L2 of its own (blocks b and
+// b + 8 share one): were consecutive entries handed to consecutive blocks, every XCD would fetch every
+// tile's bricks from memory for itself.  Instead a run of consecutive entries stays on one XCD: four
+// blocks of that XCD take a quarter of the run each, and the groups of a block work on neighbouring
+// entries at any time.  A group takes up to four entries of a run in turn (one when the queue is short
+// enough for every entry to have a group of its own).  Calls f(entry, valid) with all lanes of the wave,
+// valid = false for a group without an entry (entry is then 0); the groups of the grid together cover
+// [0, entries) once.  Correct for any placement of the blocks, only the cache hit rate depends on it.
+// gridDim.x must be a multiple of 32.
+template <int GROUPS, typename F>
 __device__ __forceinline__ void for_queue_entries(uint32_t entries, F f)
 {
-    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t group = (threadIdx.x >> 6) * GROUPS + ((threadIdx.x & 63u) / (64u / GROUPS));   // within the block
+    constexpr uint32_t per_block = 4u * GROUPS;
     const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;       // slot: index among the blocks of this XCD
     const uint32_t quads = gridDim.x >> 5;                               // runs one XCD works on at a time
-    const uint32_t all_waves = gridDim.x * 4u;
-    const uint32_t per_wave = min(4u, max(1u, (entries + all_waves - 1u) / all_waves));
-    const uint32_t run = 16u * per_wave;
+    const uint32_t all_groups = gridDim.x * per_block;
+    const uint32_t per_group = min(4u, max(1u, (entries + all_groups - 1u) / all_groups));
+    const uint32_t run = 4u * per_block * per_group;
     const uint32_t runs = (entries + run - 1u) / run;
     for (uint32_t q = slot >> 2; q * 8u + xcd < runs; q += quads) {
-        const uint32_t first = (q * 8u + xcd) * run + (slot & 3u) * 4u * per_wave;
-        for (uint32_t k = 0; k < per_wave; k++) {
-            const uint32_t entry = first + k * 4u + wave;
-            if (entry < entries) f(entry);
+        const uint32_t first = (q * 8u + xcd) * run + (slot & 3u) * per_block * per_group;
+        for (uint32_t k = 0; k < per_group; k++) {
+            const uint32_t entry = first + k * per_block + group;
+            const bool valid = entry < entries;
+            f(valid ? entry : 0u, valid);
         }
     }
 }
@@ -1608,10 +1666,10 @@ __device__ __forceinline__ void for_queue_entries(uint32_t entries, F f)
 // The rays k_march_fast ran out of lane budget on, one wave per ray; rays still undecided at the back
 // join the replay queue.
 #ifndef VR_LONG_MIN_WAVES
-#define VR_LONG_MIN_WAVES 1
+#define VR_LONG_MIN_WAVES 4
 #endif
-template <typename T, bool STATS, bool SHADE>
-__global__ __launch_bounds__(256, VR_LONG_MIN_WAVES) void k_march_long(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
+template <typename T, int G, bool STATS, bool SHADE>
+__global__ __launch_bounds__(256, (STATS || SHADE) ? 1 : VR_LONG_MIN_WAVES) void k_march_long(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
                                                    float4 border, const LutInfo *__restrict__ info,
                                                    uint32_t *__restrict__ out, Counters *ctr, uint32_t *touched,
                                                    uint32_t *__restrict__ queue, const LongRay *__restrict__ long_queue)
@@ -1619,12 +1677,14 @@ __global__ __launch_bounds__(256, VR_LONG_MIN_WAVES) void k_march_long(VolumeVie
     __shared__ float4 s_lut[kLutLds];
     stage_lut(s_lut, lut, border);
     const Decider dec(info);
-    const int lane = threadIdx.x & 63;
-    for_queue_entries(ctr->long_count, [&](uint32_t entry) {
+    const int sub = threadIdx.x & (G - 1);
+    const uint32_t entries = ctr->long_count;
+    if (entries == 0u) return;
+    for_queue_entries<64 / G>(entries, [&](uint32_t entry, bool valid) {
         const LongRay e = long_queue[entry];
         uint32_t rgba;
-        const bool decided = continue_ray<T, STATS, false, SHADE>(vol, fp, s_lut, dec, ctr, touched, e, rgba);
-        if (lane == 0) {
+        const bool decided = continue_ray<T, G, STATS, false, SHADE>(vol, fp, s_lut, dec, ctr, touched, e, valid, rgba);
+        if (valid && sub == 0) {
             if (decided) out[e.pixel_id] = rgba;
             else queue[atomicAdd(&ctr->replay_count, 1u)] = e.pixel_id;
         }
@@ -1642,8 +1702,8 @@ __global__ __launch_bounds__(256) void k_replay_exact(VolumeView vol, FrameParam
     __shared__ float4 s_lut[kLutLds];
     stage_lut(s_lut, lut, border);
     const Decider dec(info);
-    for_queue_entries(ctr->replay_count, [&](uint32_t entry) {
-        replay_ray<T, STATS, false, SHADE>(vol, fp, s_lut, dec, out, ctr, touched, queue[entry], tiles, tiles_x);
+    for_queue_entries<1>(ctr->replay_count, [&](uint32_t entry, bool valid) {
+        if (valid) replay_ray<T, STATS, false, SHADE>(vol, fp, s_lut, dec, out, ctr, touched, queue[entry], tiles, tiles_x);
     });
 }
 

@@ -95,10 +95,10 @@ __global__ __launch_bounds__(256) void k_partial_long(VolumeView vol, FrameParam
     __shared__ float4 s_lut[kLutLds];
     stage_lut(s_lut, lut, border);
     const Decider dec(info);
-    for_queue_entries(ctr->long_count, [&](uint32_t entry) {
+    for_queue_entries<1>(ctr->long_count, [&](uint32_t entry, bool valid) {
         const LongRay e = long_queue[entry];
         uint32_t rgba;
-        continue_ray<T, false, true>(vol, fp, s_lut, dec, ctr, nullptr, e, rgba, out);
+        continue_ray<T, 64, false, true>(vol, fp, s_lut, dec, ctr, nullptr, e, valid, rgba, out);
     });
 }
 
