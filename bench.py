@@ -40,6 +40,9 @@ if ROOT not in sys.path:
 
 TF_X = (0.0, 120.0, 300.0, 483.0)
 TF_GRAPHS = [list(zip(TF_X, c)) for c in ((0, .9, 1, 1), (0, .3, .8, 1), (0, .1, .5, 1), (0, 0, .05, .6))]
+# a second table, not the headline workload: low alpha everywhere, no ray becomes opaque
+TRANSLUCENT_X = (0.0, 60.0, 300.0, 483.0)
+TRANSLUCENT_GRAPHS = [list(zip(TRANSLUCENT_X, c)) for c in ((0.2, .9, 1, 1), (0.1, .3, .8, 1), (0.3, .1, .5, 1), (0.0, 0.004, 0.01, 0.02))]
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
 METRIC = "Gsamples/s + frames/s, 2048^3 u16 @ 4K, 1/2/4/8 MI355X; % HBM roofline"
 
@@ -116,6 +119,9 @@ def parse_args(argv=None):
     ap.add_argument("--mode", choices=("fast", "reference", "reference_skip"), default="fast")
     ap.add_argument("--schedule", choices=("direct_send", "binary_swap"), default="binary_swap",
                     help="c5: how the partial images are exchanged (binary swap is the schedule the benchmark names)")
+    ap.add_argument("--table", choices=("benchmark", "translucent"), default="benchmark",
+                    help="transfer function: the benchmark's 4-point table, or one with low alpha everywhere (not the headline "
+                         "workload: every tap of every ray has to be marched)")
     ap.add_argument("--stats-frames", type=int, default=12, help="frames measured with counters for the roofline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tune", action="store_true",
@@ -193,7 +199,8 @@ class Setup:
             "%d frames round the 360-frame orbit at 1 deg/step" % args.steps
         text = "%s: %d^3 %s Shepp-Logan phantom, %dx%d, %d samples/ray%s, 4-point transfer function, %s, mode %s%s%s" % (
             args.config, c["volume"], "uint8" if c["dtype"] == 1 else "uint16", c["width"], c["height"], c["samples"],
-            " (half-voxel on the diagonal)" if CONFIGS[args.config]["samples"] is None else "", cam, args.mode,
+            " (half-voxel on the diagonal)" if CONFIGS[args.config]["samples"] is None else "", cam,
+            args.mode + (", translucent table (not the headline workload)" if args.table == "translucent" else ""),
             ", gradient lighting on" if args.shading else "", extra)
         if self.overridden:
             text += " [not the named configuration: %s overridden]" % ", ".join(self.overridden)
@@ -227,7 +234,7 @@ def run_sort_first(args, su):
     ctx.synchronize()
     del raw
     torch.cuda.empty_cache()
-    ctx.update_transfer_function(TF_GRAPHS, reset_state=True)
+    ctx.update_transfer_function(TRANSLUCENT_GRAPHS if args.table == "translucent" else TF_GRAPHS, reset_state=True)
     ctx.set_sampling(samples, (0.0, 0.0, 0.0, 0.0))
     ctx.set_mode(mode)
     if args.shading:

@@ -390,6 +390,41 @@ def test_translucent_table_fast(ctx, oracle):
     print(st)
 
 
+def test_fast_mode_gives_way_under_a_translucent_table(ctx, oracle):
+    """Low alpha everywhere: no ray becomes opaque, most pixels of the first fast frame end in the replay.
+    From the second frame on fast mode renders through the skipping reference-order march: same bytes, no
+    more taps than that mode fetches.  A new table re-arms the fast path."""
+    xs = (0.0, 60.0, 300.0, 483.0)
+    translucent = [list(zip(xs, c)) for c in ((0.2, .9, 1, 1), (0.1, .3, .8, 1), (0.3, .1, .5, 1), (0.0, 0.004, 0.01, 0.02))]
+    vox = oracle.phantom(96, np.uint16)
+    w, h, samples = 160, 120, 333
+    ctx.upload_volume(vox)
+    ctx.update_transfer_function(translucent, reset_state=True)
+    ctx.set_camera(*cf.CAMERAS["h30_v20"])
+    ctx.set_sampling(samples)
+    ctx.set_mode(2)
+    ref, st2 = ctx.render(w, h, stats=True)
+    ctx.update_transfer_function(translucent, reset_state=True)     # re-arms the probe
+    ctx.set_mode(1)
+    first, st_first = ctx.render(w, h, stats=True)
+    assert np.array_equal(first, ref)
+    assert st_first["replay_rays"] > 0.1 * w * h                    # the probe frame paid for the replay
+    second, st = ctx.render(w, h, stats=True)
+    assert np.array_equal(second, ref)
+    assert st["replay_rays"] == 0 and st["long_rays"] == 0 and sum(st["rays_by_lane_taps"]) == 0
+    assert st["samples_evaluated"] <= 1.1 * st2["samples_evaluated"]
+    vol, _ = oracle.normalize(vox)
+    lut = np.zeros((256, 4), np.float32)
+    oracle.lut_update(lut, translucent)
+    vp, m = oracle.camera(*cf.CAMERAS["h30_v20"], w, h)
+    assert np.array_equal(second, oracle.render(vol, lut, vp[4:8], m, w, h, samples))
+    # the benchmark table afterwards: the lane march runs again (only it counts rays by their taps)
+    ctx.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+    ctx.render(w, h)
+    _, st = ctx.render(w, h, stats=True)
+    assert sum(st["rays_by_lane_taps"]) == st["rays_hit"] > 0
+
+
 def test_count_hit_rays(ctx, oracle):
     ctx.upload_volume(np.ones((4, 4, 4), np.uint8))
     for cam in cf.CAMERAS.values():
@@ -887,3 +922,46 @@ def test_two_frames_in_flight_render_the_same_frames(ctx, oracle, torch):
     ctx.set_pipeline(1)
     assert np.array_equal(ctx.render(w, h), pair[1].cpu().numpy())
     assert not np.array_equal(pair[1].cpu().numpy(), alone[0])
+
+
+def test_eight_pipelined_contexts_in_one_process(vr, oracle, torch):
+    """Eight contexts with two frames in flight each: sixteen streams of this library in one process, more
+    than the four hardware queues a process gets (GPU_MAX_HW_QUEUES), so the runtime multiplexes them.
+    Every context renders frames in turn, interleaved with the others; all frames equal the one rendered
+    alone; everything is destroyed again."""
+    n, w, h, samples = 64, 160, 120, 200
+    vox = oracle.phantom(n, np.uint16)
+    cams = [(math.radians(-150.0 + 40.0 * k), math.radians(15.0)) for k in range(3)]
+    with vr.VolumeRenderer(0) as c:
+        c.upload_volume(vox)
+        c.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+        c.set_sampling(samples)
+        c.set_mode(1)
+        alone = []
+        for cam in cams:
+            c.set_camera(*cam)
+            alone.append(c.render(w, h))
+    ctxs, bufs = [], []
+    try:
+        for k in range(8):
+            c = vr.VolumeRenderer(0)
+            c.upload_volume(vox)
+            c.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+            c.set_sampling(samples)
+            c.set_mode(1)
+            c.set_pipeline(2)
+            ctxs.append(c)
+            bufs.append([torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda") for _ in cams])
+        torch.cuda.synchronize()
+        for f, cam in enumerate(cams):          # frame f of every context before frame f + 1 of any
+            for c, b in zip(ctxs, bufs):
+                c.set_camera(*cam)
+                c.render_device(w, h, b[f].data_ptr())
+        for c in ctxs:
+            c.synchronize()
+        for k, b in enumerate(bufs):
+            for f in range(len(cams)):
+                assert np.array_equal(b[f].cpu().numpy(), alone[f]), (k, f)
+    finally:
+        for c in ctxs:
+            c.close()

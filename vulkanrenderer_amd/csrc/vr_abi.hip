@@ -48,6 +48,13 @@ struct vr_ctx {
     size_t tiles_cap = 0;
     bool tile_clip = true;
     bool occupancy_dirty = true;
+    // Fast mode pays off when rays become opaque or leave the object early.  With a table of low alpha
+    // everywhere neither happens: every tap is marched, the rounding bound of the decision grows with the
+    // number of taps blended, and the undecided rays are marched a second and third time by the replay.
+    // The first fast frame after a change of table, border, shading, sampling or volume is therefore a
+    // probe: if more than a tenth of its pixels had to be replayed, fast frames are rendered by the skipping
+    // reference-order march (same bytes, every tap once) until the next such change.
+    bool fast_probe = true, fast_fallback = false;
     int dtype = 0, nx = 0, ny = 0, nz = 0, nbx = 0, nby = 0, nbz = 0;
     // sort-last: the bricks held are the box [brick_lo, brick_lo + (nbx, nby, nbz)) of the volume's grid
     bool sub = false;
@@ -384,6 +391,8 @@ int refresh_occupancy(vr_ctx *ctx)
     VR_HIP(ctx, hipMemcpyAsync(&ctx->occ_count, ctx->d_occ_count, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     VR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->occupancy_dirty = false;
+    ctx->fast_probe = true;
+    ctx->fast_fallback = false;
     return VR_OK;
 }
 
@@ -440,10 +449,11 @@ void launch_frame_as(vr_ctx *ctx, const vr::FrameParams &fp, uint32_t *d_out, co
     const int slot = (int)(ctx->frames % (uint64_t)vr_ctx::kRing);
     ctx->frames++;
     (void)hipEventRecord(ctx->ring_a[slot], s);
-    if (ctx->mode == VR_MODE_REFERENCE_ORDER) {
+    const int mode = (ctx->mode == VR_MODE_FAST && ctx->fast_fallback) ? VR_MODE_REFERENCE_SKIP : ctx->mode;
+    if (mode == VR_MODE_REFERENCE_ORDER) {
         hipLaunchKernelGGL((vr::k_march_exact<T, false, STATS, SHADE>), grid, block, 0, s, vol, fp, lut, border, d_out, fb.counters, ctx->touched);
         (void)hipEventRecord(ctx->ring_b[slot], s);
-    } else if (ctx->mode == VR_MODE_REFERENCE_SKIP) {
+    } else if (mode == VR_MODE_REFERENCE_SKIP) {
         hipLaunchKernelGGL((vr::k_march_exact<T, true, STATS, SHADE>), grid, block, 0, s, vol, fp, lut, border, d_out, fb.counters, ctx->touched);
         (void)hipEventRecord(ctx->ring_b[slot], s);
     } else {
@@ -897,6 +907,10 @@ int vr_set_sampling(vr_ctx *ctx, int samples_per_ray, const float tf_border_rgba
 {
     if (!ctx) return VR_ERR_ARG;
     if (samples_per_ray < 0 || samples_per_ray > (1 << 20)) return fail(ctx, VR_ERR_ARG, "samples_per_ray out of range");
+    if (ctx->samples != samples_per_ray) {
+        ctx->fast_probe = true;
+        ctx->fast_fallback = false;
+    }
     ctx->samples = samples_per_ray;
     if (tf_border_rgba && std::memcmp(ctx->border, tf_border_rgba, sizeof ctx->border) != 0) {
         std::memcpy(ctx->border, tf_border_rgba, sizeof ctx->border);
@@ -977,7 +991,11 @@ static int render_impl(vr_ctx *ctx, int width, int height, int x0, int y0, int x
         d_out = ctx->frame;
     }
     const bool want_stats = stats != nullptr;
-    const bool fast = ctx->mode == VR_MODE_FAST;
+    if (ctx->mode != VR_MODE_REFERENCE_ORDER && ctx->occupancy_dirty) {
+        drain(ctx);
+        if (int rc = refresh_occupancy(ctx)) return rc;    // also re-arms the fast mode's probe
+    }
+    const bool fast = ctx->mode == VR_MODE_FAST && !ctx->fast_fallback;
     unsigned char *sp = nullptr;
     if (use_static) {
         const int tile_px = 1 << vr::kRangeShift;
@@ -1012,9 +1030,7 @@ static int render_impl(vr_ctx *ctx, int width, int height, int x0, int y0, int x
     // Two frames in flight: only for fast frames into device memory without counters.  Every other
     // frame first lets the frames in flight finish and then runs on the one stream.
     const bool piped = fast && out_is_device && !want_stats && ctx->pipeline_depth == 2 && !use_static;
-    if (!piped || ctx->occupancy_dirty) drain(ctx);
-    if (ctx->mode != VR_MODE_REFERENCE_ORDER)
-        if (int rc = refresh_occupancy(ctx)) return rc;
+    if (!piped) drain(ctx);
     FrameBuffers fb{ctx->counters, ctx->queue, ctx->long_queue, ctx->tiles, ctx->stream, nullptr};
     if (use_static)
         fb = FrameBuffers{reinterpret_cast<vr::Counters *>(sp + static_scratch::kCountersAt),
@@ -1070,6 +1086,16 @@ static int render_impl(vr_ctx *ctx, int width, int height, int x0, int y0, int x
         ctx->last_set = -1;
     }
     VR_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+
+    if (fast && ctx->fast_probe && pixels >= 4096) {
+        // the probe frame: how many of its pixels went through the replay?
+        vr::Counters c;
+        if (piped) VR_HIP(ctx, hipStreamSynchronize(ctx->tail_stream));
+        VR_HIP(ctx, hipMemcpyAsync(&c, fb.counters, sizeof c, hipMemcpyDeviceToHost, ctx->stream));
+        VR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->fast_probe = false;
+        ctx->fast_fallback = (size_t)c.replay_count * 10u > pixels;
+    }
 
     if (!out_is_device) {
         VR_HIP(ctx, hipMemcpyAsync(out, d_out, pixels * 4, hipMemcpyDeviceToHost, ctx->stream));
