@@ -119,6 +119,9 @@ def parse_args(argv=None):
     ap.add_argument("--mode", choices=("fast", "reference", "reference_skip"), default="fast")
     ap.add_argument("--schedule", choices=("direct_send", "binary_swap"), default="binary_swap",
                     help="c5: how the partial images are exchanged (binary swap is the schedule the benchmark names)")
+    ap.add_argument("--balance", choices=("occupied", "even"), default="occupied",
+                    help="c5: how the brick grid is cut into boxes: planes chosen so that every box holds about the same "
+                         "number of occupied bricks (counted on the GPUs first), or an even split")
     ap.add_argument("--table", choices=("benchmark", "translucent"), default="benchmark",
                     help="transfer function: the benchmark's 4-point table, or one with low alpha everywhere (not the headline "
                          "workload: every tap of every ray has to be marched)")
@@ -424,6 +427,15 @@ def run_sort_last(args, su):
     torch.cuda.empty_cache()
     ctx.update_transfer_function(TF_GRAPHS, reset_state=True)
     ctx.set_sampling(samples, (0.0, 0.0, 0.0, 0.0))
+    if args.balance == "occupied" and world > 1:
+        # the boxes of the even split count their occupied bricks, one all-reduce sums the grids, every rank
+        # derives the same cut planes and loads its box of that split instead
+        nb = vr.brick_grid(n, n, n)
+        cell = max(1, min(8, min(b // (2 * g) for b, g in zip(nb, grid))))
+        counts = sl.occupied_counts(ctx, nb, cell, device, host_staging=su.backend != "nccl")
+        cuts = sl.balanced_cuts(counts, cell, nb, grid)
+        lo, hi = sl.upload_phantom_box(ctx, n, c["dtype"], grid, box, device, cuts=cuts)
+        torch.cuda.empty_cache()
     t_setup = time.perf_counter() - t_setup
     engine = sl.HipEngine(ctx, w, h)
     fr = sl.SortLastFrame(engine, w, h, rank, world, device, grid=grid, schedule=schedule, host_staging=su.backend != "nccl")
@@ -499,7 +511,7 @@ def run_sort_last(args, su):
                 "name": args.config,
                 "volume": [n, n, n], "image": [w, h], "samples_per_ray": samples,
                 "parallelism": "sort-last x%d (boxes of bricks %dx%dx%d, %s over RCCL, byte-exact re-march of undecided pixels)" % (world, grid[0], grid[1], grid[2], schedule),
-                "bricks_of_rank0": [list(lo), list(hi)],
+                "bricks_of_rank0": [list(lo), list(hi)], "balance": args.balance if world > 1 else "one box",
                 "setup_s": round(t_setup, 2),
             },
             "stages": stages,

@@ -260,6 +260,12 @@ int vr_subvolume_voxels(int nx, int ny, int nz, const int brick_lo[3], const int
  * context renders with vr_render_partial only. */
 int vr_upload_subvolume_device(vr_ctx *ctx, const void *d_voxels, int dtype, int nx, int ny, int nz,
                                const int brick_lo[3], const int brick_hi[3], float max_value);
+/* For cutting boxes of equal work: the bricks of this context (whole volume or box) that the current
+ * transfer function does not make transparent, counted per cube of cell_bricks^3 bricks of the WHOLE
+ * volume's brick grid and ADDED to d_counts (device, uint32, ceil(bricks[k] / cell_bricks) cubes per axis,
+ * x fastest; the caller clears it and sums the contexts' grids, e.g. with one all-reduce).  Asynchronous on
+ * the context's stream. */
+int vr_occupied_brick_counts(vr_ctx *ctx, int cell_bricks, uint32_t *d_counts);
 /* Step 1.  out: width*height*5 floats, host (synchronous) or device pointer.  Also valid on a
  * context holding the whole volume (one box). */
 int vr_render_partial(vr_ctx *ctx, int width, int height, float *out, int out_is_device);

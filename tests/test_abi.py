@@ -59,3 +59,18 @@ def test_binding_argument_counts_match_the_header():
         assert len(argtypes) == count, (name, len(argtypes), count)
         checked += 1
     assert checked == len(vr.ABI_SYMBOLS)
+
+
+def test_multi_gpu_library_exports_every_declared_symbol():
+    """libvr_mg.so (include/vr_mg.h): loads, exports every declared function, binding arities match."""
+    from vulkanrenderer_amd import multigpu as mg
+    text = open(os.path.join(cf.ROOT, "include", "vr_mg.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = re.findall(r"\b(vrmg_[a-z_0-9]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S)
+    assert sorted(n for n, _ in protos) == sorted(mg.MG_SYMBOLS)
+    L = mg.lib()
+    for name, params in protos:
+        params = params.strip()
+        count = 0 if params in ("", "void") else len(params.split(","))
+        assert len(getattr(L, name).argtypes) == count, name
+    assert mg.UNIQUE_ID_BYTES == 128

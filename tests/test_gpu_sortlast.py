@@ -294,6 +294,102 @@ def test_single_rank_over_rccl(vr, torch, oracle, schedule):
     assert np.array_equal(got, want), cf.frame_report(got, want)
 
 
+def test_multi_gpu_layer_behind_the_c_abi(vr, torch, oracle):
+    """libvr_mg.so with one rank: every RCCL call of the sort-first and the sort-last frame is issued (sends
+    to itself, all-gathers and all-reduces over one rank) and the frames equal the single-context frame."""
+    from vulkanrenderer_amd import multigpu as mg
+    from vulkanrenderer_amd import sortlast as sl
+    n, w, h, samples = 64, 200, 150, 160
+    cam = cf.CAMERAS["hm135_vm60"]
+    vox = oracle.phantom(n, np.uint16)
+    want = whole_frame(vr, vox, cam, w, h, samples)
+    frame = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    with vr.VolumeRenderer(0) as c:
+        c.upload_volume(vox)
+        c.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+        c.set_sampling(samples)
+        c.set_camera(*cam)
+        c.set_mode(vr.MODE_FAST)
+        with mg.MultiGpu(c, mg.unique_id(), 0, 1) as m:
+            for pipeline in (1, 2):
+                c.set_pipeline(pipeline)
+                frame.zero_()
+                torch.cuda.synchronize()
+                m.render_sort_first(w, h, frame.data_ptr())
+                c.synchronize()
+                assert np.array_equal(frame.cpu().numpy(), want), pipeline
+            with pytest.raises(vr.VrError):
+                m.render_sort_last(w, h, mg.DIRECT_SEND, frame.data_ptr())       # no box grid yet
+    with vr.VolumeRenderer(0) as c:
+        sl.upload_box_of(c, vox, (1, 1, 1), (0, 0, 0), "cuda")
+        c.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+        c.set_sampling(samples)
+        c.set_camera(*cam)
+        with mg.MultiGpu(c, mg.unique_id(), 0, 1) as m:
+            with pytest.raises(vr.VrError):
+                m.set_box_grid((2, 1, 1))
+            m.set_box_grid((1, 1, 1))
+            for schedule in (mg.DIRECT_SEND, mg.BINARY_SWAP):
+                frame.zero_()
+                torch.cuda.synchronize()
+                remarched = m.render_sort_last(w, h, schedule, frame.data_ptr())
+                c.synchronize()
+                assert np.array_equal(frame.cpu().numpy(), want), schedule
+                assert 0 < remarched < 0.05 * w * h
+
+
+def test_multi_gpu_example_program(tmp_path):
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "multi_gpu")
+    if not os.path.exists(exe):
+        pytest.fail("examples/multi_gpu is not built: make -C vulkanrenderer_amd/csrc")
+    res = subprocess.run([exe, "--rank", "0", "--world", "1", "--id-file", str(tmp_path / "id"), "--phantom", "64", "--size", "160x120",
+                          "--out", str(tmp_path / "frame.ppm")], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert res.stdout.count("identical to the single-GPU frame") == 3, res.stdout
+    assert os.path.getsize(str(tmp_path / "frame.ppm")) > 160 * 120 * 3
+
+
+def test_occupied_brick_counts(vr, torch, oracle):
+    """vr_occupied_brick_counts: the boxes' counts add up to the whole volume's, which equal numpy's count of the
+    bricks whose value range reaches the table's first non-transparent entry."""
+    from vulkanrenderer_amd import sortlast as sl
+    n, cell = 72, 2
+    vox = oracle.phantom(n, np.uint16)
+    nb = vr.brick_grid(n, n, n)
+    with vr.VolumeRenderer(0) as c:
+        c.upload_volume(vox)
+        c.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+        whole = sl.occupied_counts(c, nb, cell, "cuda")
+    total = np.zeros_like(whole)
+    grid = (2, 2, 1)
+    for r in range(4):
+        with vr.VolumeRenderer(0) as c:
+            sl.upload_box_of(c, vox, grid, sl.box_of_rank(r, grid), "cuda")
+            c.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+            total += sl.occupied_counts(c, nb, cell, "cuda")
+    assert np.array_equal(total, whole) and whole.sum() > 0
+    assert whole.shape == tuple(-(-b // cell) for b in nb[::-1])
+    # the exterior of the phantom is exactly zero and transparent: whole corners of the grid are empty
+    assert whole[0, 0, 0] == 0 and whole[whole.shape[0] // 2, whole.shape[1] // 2, whole.shape[2] // 2] > 0
+    cuts = sl.balanced_cuts(whole, cell, nb, (2, 2, 2))
+    ctxs = []
+    try:
+        for r in range(8):
+            c = vr.VolumeRenderer(0)
+            sl.upload_box_of(c, vox, (2, 2, 2), sl.box_of_rank(r, (2, 2, 2)), "cuda", cuts=cuts)
+            c.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+            c.set_sampling(150)
+            c.set_camera(*cf.CAMERAS["h30_v20"])
+            ctxs.append(c)
+        got, _, _, _ = sort_last_frame(vr, torch, ctxs, (2, 2, 2), 96, 72)
+    finally:
+        for c in ctxs:
+            c.close()
+    assert np.array_equal(got, whole_frame(vr, vox, cf.CAMERAS["h30_v20"], 96, 72, 150))
+
+
 def test_full_size_split_equals_whole(vr, torch):
     """1024^3 u16 at 1920x1080, eight boxes: the frame equals the single-context one."""
     from vulkanrenderer_amd import sortlast as sl

@@ -19,7 +19,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, width, height, samples, schedule, grid, camera, result_path):
+def _worker(rank, world, port, n, width, height, samples, schedule, grid, camera, result_path, balanced=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["OMP_NUM_THREADS"] = "1"
@@ -27,7 +27,7 @@ def _worker(rank, world, port, n, width, height, samples, schedule, grid, camera
     try:
         from oracle import vr_oracle as o
         from sortlast_cpu_engine import OracleEngine
-        from vulkanrenderer_amd.sortlast import SortLastFrame, box_of_rank, brick_box
+        from vulkanrenderer_amd.sortlast import SortLastFrame, balanced_cuts, box_of_rank, brick_box
 
         vol, _ = o.normalize(o.phantom(n, np.uint8))
         lut = np.zeros((256, 4), np.float32)
@@ -35,6 +35,15 @@ def _worker(rank, world, port, n, width, height, samples, schedule, grid, camera
         vp, m = o.camera(*cf.CAMERAS[camera], width, height)
         bricks = ((n + 4 + 7) // 8,) * 3
         lo, hi = brick_box(bricks, grid, box_of_rank(rank, grid))
+        if balanced:
+            # uneven boxes: planes that balance the voxels above the table's threshold, per cube of 1^3 bricks
+            vox = o.phantom(n, np.uint8)
+            pad = np.zeros((bricks[2] * 8, bricks[1] * 8, bricks[0] * 8), np.uint8)
+            pad[2:2 + n, 2:2 + n, 2:2 + n] = vox
+            occ = (pad.reshape(bricks[2], 8, bricks[1], 8, bricks[0], 8) > 60).any(axis=(1, 3, 5)).astype(np.float64)
+            occ[:, bricks[1] // 2:, : bricks[0] // 2] *= 5.0          # and lean to one side, so that the planes move
+            cuts = balanced_cuts(occ, 1, bricks, grid)
+            lo, hi = cuts.box(box_of_rank(rank, grid))
         sl = SortLastFrame(None, width, height, rank, world, "cpu", grid=grid, schedule=schedule)
         sl.e = OracleEngine(vol, lut, vp[4:8], m, width, height, samples, lo, hi, sl.padded)
         frame = sl.render()
@@ -65,6 +74,43 @@ def test_sort_last_frame_equals_the_single_process_frame(tmp_path, world, schedu
     got, want = np.load(path)
     assert want[..., :3].any()
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("world,schedule,grid,camera", [(8, "binary_swap", (2, 2, 2), "hm135_vm60"), (8, "direct_send", (2, 2, 2), "h30_v20"),
+                                                        (4, "binary_swap", (4, 1, 1), "h30_v20"), (6, "direct_send", (3, 2, 1), "top")])
+def test_boxes_of_unequal_size(tmp_path, world, schedule, grid, camera):
+    """Boxes cut by planes that balance the occupied bricks (a k-d split: z planes, per layer y planes, per
+    cell x planes): both schedules and the re-march still give the single-process frame."""
+    path = str(tmp_path / "frame.npy")
+    mp.spawn(_worker, args=(world, _free_port(), 40, 40, 36, 50, schedule, grid, camera, path, True), nprocs=world, join=True)
+    got, want = np.load(path)
+    assert want[..., :3].any()
+    assert np.array_equal(got, want)
+
+
+def test_balanced_cuts_tile_the_grid():
+    from vulkanrenderer_amd.sortlast import balanced_cuts, box_of_rank, brick_box, even_cuts
+    rng = np.random.default_rng(3)
+    bricks, cell = (65, 66, 70), 8
+    counts = rng.integers(0, 50, size=(9, 9, 9)).astype(np.float64)
+    counts[:, 5:, :] *= 6.0
+    for grid in ((2, 2, 2), (4, 2, 1), (3, 1, 2), (1, 1, 1), (2, 1, 1)):
+        cuts = balanced_cuts(counts, cell, bricks, grid)
+        covered = np.zeros(bricks[::-1], np.int32)
+        for r in range(grid[0] * grid[1] * grid[2]):
+            lo, hi = cuts.box(box_of_rank(r, grid))
+            assert all(h > l for l, h in zip(lo, hi))
+            covered[lo[2]:hi[2], lo[1]:hi[1], lo[0]:hi[0]] += 1
+        assert (covered == 1).all(), grid
+    # the heavy half gets the thinner boxes
+    cuts = balanced_cuts(counts, cell, bricks, (1, 2, 1))
+    (lo0, hi0), (lo1, hi1) = cuts.box((0, 0, 0)), cuts.box((0, 1, 0))
+    assert hi0[1] - lo0[1] > hi1[1] - lo1[1]
+    e = even_cuts((9, 17, 33), (2, 2, 2))
+    for r in range(8):
+        assert e.box(box_of_rank(r, (2, 2, 2))) == brick_box((9, 17, 33), (2, 2, 2), box_of_rank(r, (2, 2, 2)))
+    with pytest.raises(ValueError):
+        balanced_cuts(counts[:1], cell, (65, 66, 8), (1, 1, 2))
 
 
 def test_decomposition_arithmetic():

@@ -30,16 +30,32 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--frames", type=int, default=24)
     ap.add_argument("--step-deg", type=float, default=15.0)
+    ap.add_argument("--balance", choices=("even", "occupied"), default="occupied",
+                    help="even: equal brick counts per box; occupied: k-d cuts with equal numbers of occupied bricks")
+    ap.add_argument("--cell", type=int, default=8, help="occupied bricks are counted per cube of this many bricks")
     a = ap.parse_args()
     grid, n, w, h = tuple(a.grid), a.volume, a.width, a.height
     world = grid[0] * grid[1] * grid[2]
     samples = int(math.ceil(2 * math.sqrt(3) * n)) - 1
     boxes = [tuple(a.box)] if a.box else [sl.box_of_rank(r, grid) for r in range(world)]
     pixels = w * h
-    out = {"volume": n, "grid": grid, "frame": [w, h], "samples_per_ray": samples, "boxes": []}
+    out = {"volume": n, "grid": grid, "frame": [w, h], "samples_per_ray": samples, "balance": a.balance, "boxes": []}
+    cuts = None
+    if a.balance == "occupied":
+        # one box after the other (one GPU stands in for all): occupied bricks of the even boxes, then the cuts
+        nb = vr.brick_grid(n, n, n)
+        total = None
+        for r in range(world):
+            with vr.VolumeRenderer(0) as c:
+                sl.upload_phantom_box(c, n, 2, grid, sl.box_of_rank(r, grid), "cuda")
+                c.update_transfer_function(TF, reset_state=True)
+                part = sl.occupied_counts(c, nb, a.cell, "cuda")
+                total = part if total is None else total + part
+        cuts = sl.balanced_cuts(total, a.cell, nb, grid)
+        out["occupied_bricks"] = int(total.sum())
     for box in boxes:
         with vr.VolumeRenderer(0) as c:
-            lo, hi = sl.upload_phantom_box(c, n, 2, grid, box, "cuda")
+            lo, hi = sl.upload_phantom_box(c, n, 2, grid, box, "cuda", cuts=cuts)
             c.update_transfer_function(TF, reset_state=True)
             c.set_sampling(samples)
             stream = torch.cuda.ExternalStream(c.stream)
@@ -103,6 +119,8 @@ def main():
         out["merge_ms"] = e0.elapsed_time(e1)
         out["decide_ms"] = e1.elapsed_time(e2)
         out["exchange_bytes_per_rank"] = (world - 1) * span * 20
+    means = [b["partial_ms_mean"] for b in out["boxes"]]
+    out["partial_ms_max_over_mean"] = max(means) / (sum(means) / len(means))
     print(json.dumps(out))
 
 

@@ -28,7 +28,7 @@ ABI_SYMBOLS = (
     "vr_phantom_generate_device", "vr_phantom_generate_box_device",
     "vr_brick_grid", "vr_subvolume_voxels", "vr_upload_subvolume_device", "vr_render_partial",
     "vr_composite_pair", "vr_composite_ordered", "vr_decide_partials", "vr_chain_stage",
-    "vr_store_chain", "vr_render_static", "vr_static_max_pixels",
+    "vr_store_chain", "vr_occupied_brick_counts", "vr_render_static", "vr_static_max_pixels",
 )
 PARTIAL_FLOATS = 5   # floats per pixel of a sort-last partial result: F0, F1, F2, Tr, S
 
@@ -116,6 +116,7 @@ def lib():
     L.vr_subvolume_voxels.argtypes = [C.c_int, C.c_int, C.c_int, i3, i3, i3, i3]
     L.vr_upload_subvolume_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, i3, i3, C.c_float]
     L.vr_render_partial.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
+    L.vr_occupied_brick_counts.argtypes = [vp, C.c_int, vp]
     L.vr_composite_pair.argtypes = [vp, C.c_int, C.c_int, u64, u64, vp, vp, C.c_int, C.c_int, vp]
     L.vr_composite_ordered.argtypes = [vp, C.c_int, C.c_int, u64, u64, vp, vp, i3, vp]
     L.vr_decide_partials.argtypes = [vp, C.c_int, C.c_int, u64, u64, vp, vp, vp, vp]
@@ -386,6 +387,10 @@ class VolumeRenderer:
     def upload_subvolume_device(self, ptr, dtype_bytes, nx, ny, nz, brick_lo, brick_hi, max_value):
         self._check(lib().vr_upload_subvolume_device(self._h, ptr, dtype_bytes, nx, ny, nz, _i3(brick_lo),
                                                      _i3(brick_hi), max_value))
+
+    def occupied_brick_counts(self, cell_bricks, counts_ptr):
+        """Adds this context's occupied bricks per cube of cell_bricks^3 bricks to a device uint32 grid."""
+        self._check(lib().vr_occupied_brick_counts(self._h, cell_bricks, counts_ptr))
 
     def render_partial(self, width, height, ptr=None):
         """Partial result of this context's box: (height*width, 5) floats.  With ptr (device memory)

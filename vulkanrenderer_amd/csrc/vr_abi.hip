@@ -1338,6 +1338,20 @@ int vr_subvolume_voxels(int nx, int ny, int nz, const int brick_lo[3], const int
     return VR_OK;
 }
 
+int vr_occupied_brick_counts(vr_ctx *ctx, int cell_bricks, uint32_t *d_counts)
+{
+    if (!ctx || !d_counts) return fail(ctx, VR_ERR_ARG, "null argument");
+    if (cell_bricks < 1) return fail(ctx, VR_ERR_ARG, "cell size must be at least one brick");
+    if (!ctx->bricks) return fail(ctx, VR_ERR_STATE, "no volume uploaded");
+    if (int rc = bind(ctx)) return rc;
+    if (int rc = refresh_occupancy(ctx)) return rc;
+    const int cnx = (bricks_along(ctx->nx) + cell_bricks - 1) / cell_bricks, cny = (bricks_along(ctx->ny) + cell_bricks - 1) / cell_bricks;
+    hipLaunchKernelGGL(vr::k_count_occupied, dim3(2048), dim3(256), 0, ctx->stream, ctx->empty[0], ctx->nbx, ctx->nby, ctx->nbz,
+                       ctx->brick_lo[0], ctx->brick_lo[1], ctx->brick_lo[2], cell_bricks, cnx, cny, d_counts);
+    VR_HIP(ctx, hipGetLastError());
+    return VR_OK;
+}
+
 int vr_upload_subvolume_device(vr_ctx *ctx, const void *d_voxels, int dtype, int nx, int ny, int nz, const int brick_lo[3],
                                const int brick_hi[3], float max_value)
 {

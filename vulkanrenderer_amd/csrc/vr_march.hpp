@@ -334,6 +334,21 @@ __global__ __launch_bounds__(256) void k_occupied_bounds(const uint32_t *__restr
     }
 }
 
+// Occupied bricks of this context's box, counted per cube of `cell`^3 bricks of the WHOLE volume's brick
+// grid (x fastest; cnx x cny cubes per slice of the count grid) and added to `counts`: what a caller that
+// splits a volume over several GPUs needs to cut boxes of equal work.  (bx0, by0, bz0): first brick of the box.
+__global__ __launch_bounds__(256) void k_count_occupied(const uint32_t *__restrict__ empty0, int nbx, int nby, int nbz, int bx0,
+                                                       int by0, int bz0, int cell, int cnx, int cny, uint32_t *counts)
+{
+    const uint32_t bricks = (uint32_t)(nbx * nby * nbz);
+    for (uint32_t b = blockIdx.x * 256u + threadIdx.x; b < bricks; b += gridDim.x * 256u) {
+        if ((empty0[b >> 5] >> (b & 31)) & 1u) continue;
+        const int x = (int)(b % (uint32_t)nbx) + bx0, y = (int)((b / (uint32_t)nbx) % (uint32_t)nby) + by0,
+                  z = (int)(b / (uint32_t)(nbx * nby)) + bz0;
+        atomicAdd(&counts[((size_t)(z / cell) * cny + (size_t)(y / cell)) * cnx + (size_t)(x / cell)], 1u);
+    }
+}
+
 // ---- depth range of the occupied bricks per pixel tile (8x8 pixels, 1 << kRangeShift) ---------------
 // Before a frame every occupied brick is projected into the image and widens, for each tile its
 // projection touches, the tile's range [near, far] of distances from the eye.  A ray then only looks

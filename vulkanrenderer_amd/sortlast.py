@@ -60,6 +60,71 @@ def brick_box(bricks, grid, box):
     return lo, hi
 
 
+class Cuts:
+    """Where the volume's brick grid is cut into a grid of boxes: one set of planes across z, then for every
+    z layer its own planes across y, then for every (z, y) cell its own planes across x (a k-d split).
+    Boxes keep their grid coordinates, so the visibility order (lexicographic in mirrored (z, y, x)) and
+    the binary-swap rounds (x pairs first, then y, then z: every merged pair is separated by one of
+    these planes and its union is again a box) are those of an even grid."""
+
+    def __init__(self, grid, z, y, x):
+        self.grid = tuple(grid)
+        self.z = [int(v) for v in z]                                   # gz + 1 brick indices
+        self.y = [[int(v) for v in row] for row in y]                  # [gz][gy + 1]
+        self.x = [[[int(v) for v in cell] for cell in row] for row in x]   # [gz][gy][gx + 1]
+
+    def box(self, box):
+        bx, by, bz = box
+        return ((self.x[bz][by][bx], self.y[bz][by], self.z[bz]), (self.x[bz][by][bx + 1], self.y[bz][by + 1], self.z[bz + 1]))
+
+
+def even_cuts(bricks, grid):
+    """The even split brick_box() describes, as Cuts."""
+    if any(b < g for b, g in zip(bricks, grid)):
+        raise ValueError("fewer bricks than boxes along an axis: %r bricks, %r boxes" % (bricks, grid))
+    edges = [[(c * b) // g for c in range(g + 1)] for b, g in zip(bricks, grid)]
+    return Cuts(grid, edges[2], [edges[1]] * grid[2], [[edges[0]] * grid[1]] * grid[2])
+
+
+def _balanced_edges(weights, parts, unit, total):
+    """Cuts a 1-D array of weights (one per `unit` bricks, covering `total` bricks) into `parts` runs of about
+    equal sum, every run at least one cell long; returns parts + 1 brick indices."""
+    cells = len(weights)
+    if cells < parts:
+        raise ValueError("fewer count cells than boxes along an axis")
+    cum = np.concatenate([[0.0], np.cumsum(np.asarray(weights, np.float64) + 1e-9)])
+    edges = [0]
+    for k in range(1, parts):
+        target = cum[-1] * k / parts
+        e = int(np.searchsorted(cum, target))
+        if e > 0 and abs(cum[e - 1] - target) <= abs(cum[min(e, cells)] - target):
+            e -= 1
+        e = max(edges[-1] + 1, min(e, cells - (parts - k)))
+        edges.append(e)
+    edges.append(cells)
+    return [min(e * unit, total) for e in edges[:-1]] + [total]
+
+
+def balanced_cuts(counts, cell_bricks, bricks, grid):
+    """Cuts with about the same number of occupied bricks in every box.  counts: [cz, cy, cx] occupied bricks
+    per cube of cell_bricks^3 bricks (vr_occupied_brick_counts, summed over the contexts); bricks: the
+    volume's brick grid (x, y, z); cut planes fall on cube boundaries."""
+    counts = np.asarray(counts, np.float64)
+    gx, gy, gz = grid
+    z = _balanced_edges(counts.sum(axis=(1, 2)), gz, cell_bricks, bricks[2])
+    ys, xs = [], []
+    for k in range(gz):
+        layer = counts[z[k] // cell_bricks: -(-z[k + 1] // cell_bricks)]
+        y = _balanced_edges(layer.sum(axis=(0, 2)), gy, cell_bricks, bricks[1])
+        ys.append(y)
+        row = []
+        for j in range(gy):
+            cell = layer[:, y[j] // cell_bricks: -(-y[j + 1] // cell_bricks)]
+            row.append(_balanced_edges(cell.sum(axis=(0, 1)), gx, cell_bricks, bricks[0]))
+        xs.append(row)
+    return Cuts(grid, z, ys, xs)
+
+
 def swap_rounds(world, grid):
     """Binary swap: per round the axis whose boxes are merged.  Needs power-of-two grid sides."""
     if any(g & (g - 1) for g in grid):
@@ -293,12 +358,12 @@ class SortLastFrame:
         return None
 
 
-def upload_phantom_box(renderer, n, dtype_bytes, grid, box, device, seed=0x5EED1234):
+def upload_phantom_box(renderer, n, dtype_bytes, grid, box, device, seed=0x5EED1234, cuts=None):
     """Generates this rank's box of the n^3 synthetic phantom on its GPU and uploads it as the
-    context's sub-volume.  The phantom's maximum is the dtype's (its brightest ellipsoid reaches it),
-    so no reduction over the ranks is needed."""
+    context's sub-volume (an even split of the brick grid unless `cuts` says otherwise).  The phantom's
+    maximum is the dtype's (its brightest ellipsoid reaches it), so no reduction over the ranks is needed."""
     from . import brick_grid, subvolume_voxels
-    lo, hi = brick_box(brick_grid(n, n, n), grid, box)
+    lo, hi = cuts.box(box) if cuts is not None else brick_box(brick_grid(n, n, n), grid, box)
     v_lo, v_hi = subvolume_voxels(n, n, n, lo, hi)
     ext = [h - l for l, h in zip(v_lo, v_hi)]
     dtype = torch.uint8 if dtype_bytes == 1 else torch.int16      # raw bits; the kernels read them as unsigned
@@ -310,12 +375,12 @@ def upload_phantom_box(renderer, n, dtype_bytes, grid, box, device, seed=0x5EED1
     return lo, hi
 
 
-def upload_box_of(renderer, voxels, grid, box, device, max_value=None):
+def upload_box_of(renderer, voxels, grid, box, device, max_value=None, cuts=None):
     """Cuts this rank's box out of a host array [nz, ny, nx] (uint8/uint16) and uploads it."""
     from . import brick_grid, subvolume_voxels
     voxels = np.asarray(voxels)
     nz, ny, nx = voxels.shape
-    lo, hi = brick_box(brick_grid(nx, ny, nz), grid, box)
+    lo, hi = cuts.box(box) if cuts is not None else brick_box(brick_grid(nx, ny, nz), grid, box)
     v_lo, v_hi = subvolume_voxels(nx, ny, nz, lo, hi)
     sub = np.ascontiguousarray(voxels[v_lo[2]: v_hi[2], v_lo[1]: v_hi[1], v_lo[0]: v_hi[0]])
     if max_value is None:
@@ -328,3 +393,20 @@ def upload_box_of(renderer, voxels, grid, box, device, max_value=None):
     renderer.upload_subvolume_device(t.data_ptr(), voxels.dtype.itemsize, nx, ny, nz, lo, hi, max_value)
     renderer.synchronize()
     return lo, hi
+
+
+def occupied_counts(renderer, n_bricks, cell_bricks, device, group=None, host_staging=False):
+    """Occupied bricks per cube of cell_bricks^3 bricks, summed over the ranks' boxes: [cz, cy, cx] (numpy).
+    The renderer must hold its (first, e.g. even) box and the transfer function the cut is for."""
+    dims = [-(-b // cell_bricks) for b in n_bricks]
+    counts = torch.zeros((dims[2], dims[1], dims[0]), dtype=torch.int32, device=device)
+    torch.cuda.synchronize(device)
+    renderer.occupied_brick_counts(cell_bricks, counts.data_ptr())
+    renderer.synchronize()
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        if host_staging:
+            h = counts.cpu()
+            dist.all_reduce(h, group=group)
+            return h.numpy()
+        dist.all_reduce(counts, group=group)
+    return counts.cpu().numpy()
