@@ -127,9 +127,9 @@ def parse_args(argv=None):
                          "workload: every tap of every ray has to be marched)")
     ap.add_argument("--stats-frames", type=int, default=12, help="frames measured with counters for the roofline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--tune", action="store_true",
-                    help="let the library pick its per-lane work budget by timing one view (vr_tune); the default "
-                         "value is the one measured best for the default workload")
+    ap.add_argument("--no-tune", action="store_true",
+                    help="skip vr_tune in the set-up (the library then picks its per-lane work budget from the size of the launch); "
+                         "frames do not depend on the value")
     ap.add_argument("--shading", action="store_true",
                     help="switch on the shader's commented-out lighting (not the headline workload: the reference renders without it)")
     return ap.parse_args(argv)
@@ -243,8 +243,10 @@ def run_sort_first(args, su):
     if args.shading:
         ctx.set_shading(True)
     lane_budget = None
-    if args.tune and mode == vr.MODE_FAST:
-        # part of the set-up: the library measures its one tuning parameter on a view of the orbit
+    ctx.set_pipeline(2)
+    if not args.no_tune and mode == vr.MODE_FAST:
+        # part of the set-up: the library measures its one tuning parameter on a view of the orbit, on this
+        # rank's share of the frame (frames are the same for every value)
         ctx.set_camera(*su.camera(45))
         lane_budget = ctx.tune(w, h, rank if world > 1 else 0, world if world > 1 else 1)
     t_setup = time.perf_counter() - t_setup

@@ -208,7 +208,8 @@ int vr_assemble_bands(vr_ctx *ctx, int width, int height, int parts, const uint8
  * Source/VulkanApplication.cpp:617-620). */
 int vr_march_kernel_times(vr_ctx *ctx, float *ms, int capacity, int *count);
 /* Picks the fast mode's one tuning parameter by measurement: renders the current camera's frame (or
- * the sort-first share part/parts of it) a few times for each candidate of the per-lane work budget
+ * the sort-first share part/parts of it) in short runs, with the frames in flight the context is set to,
+ * for each candidate of the per-lane work budget
  * -- how long a lane marches its ray before a whole wave takes it over -- and keeps the fastest.
  * Frames are identical for every value; only the time changes with volume, table and image size.
  * Without this call the budget follows the size of the launch (small frames hand rays over early).

@@ -25,10 +25,11 @@ out = torch.empty(w * h * 4, dtype=torch.uint8, device="cuda")
 torch.cuda.synchronize()
 frames = 36
 out2 = torch.empty(w * h * 4, dtype=torch.uint8, device="cuda")
-for depth in (1, 2):
+PARTS = [int(x) for x in os.environ.get("BAND_PARTS", "1,2,4,8").split(",")]
+for depth in [int(x) for x in os.environ.get("BAND_DEPTHS", "1,2").split(",")]:
   ctx.set_pipeline(depth)
   print("frames in flight:", depth, flush=True)
-  for parts in (1, 2, 4, 8):
+  for parts in PARTS:
     worst = 0.0
     for part in range(parts):
         for i in range(2):

@@ -5,6 +5,7 @@
 #include "../../include/vr_abi.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cerrno>
 #include <climits>
 #include <cmath>
@@ -1194,36 +1195,45 @@ int vr_tune(vr_ctx *ctx, int width, int height, int part, int parts, int *chosen
     }
     if (int rc = bind(ctx)) return rc;
     const size_t pixels = (size_t)width * (size_t)rows_of_part(height, part, parts);
-    uint8_t *scratch = nullptr;
-    VR_HIP(ctx, hipMalloc(&scratch, pixels * 4));
-    const int mode = ctx->mode, depth = ctx->pipeline_depth, before = ctx->lane_budget;
+    uint8_t *scratch[2] = {nullptr, nullptr};
+    VR_HIP(ctx, hipMalloc(&scratch[0], pixels * 4));
+    if (hipMalloc(&scratch[1], pixels * 4) != hipSuccess) {
+        (void)hipFree(scratch[0]);
+        return fail(ctx, VR_ERR_HIP, "hipMalloc failed");
+    }
+    const int mode = ctx->mode, before = ctx->lane_budget;
     ctx->mode = VR_MODE_FAST;
-    ctx->pipeline_depth = 1;
     // How long a lane stays with its ray before it hands it to a wave of its own: the best value
-    // depends on how the rays' lengths are spread, i.e. on volume, table, image size and share.
+    // depends on how the rays' lengths are spread and on how many waves the launch has, i.e. on volume,
+    // table, image size and share.  Each candidate renders a run of frames the way the caller will (one
+    // or two frames in flight, as set) and is judged by the wall time of the run.
     const int candidates[] = {8, 16, 32, 48, 64, 96, 128, 160};
-    int best = before > 0 ? before : vr::kLaneBudget, rc = VR_OK;
-    float best_ms = 3.0e38f;
+    constexpr int kRun = 6;
+    int best = before > 0 ? before : lane_budget_for(ctx, 0), rc = VR_OK;
+    double best_s = 1.0e300;
     for (int budget : candidates) {
         ctx->lane_budget = budget;
-        float fastest = 3.0e38f;
-        for (int rep = 0; rep < 3 && rc == VR_OK; rep++) {      // the first one also warms the caches
-            rc = render_impl(ctx, width, height, 0, 0, width, height, part, parts, scratch, 1, nullptr);
-            if (rc == VR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, VR_ERR_HIP, "synchronize failed");
-            float ms = 0.0f;
-            if (rc == VR_OK && hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) != hipSuccess) rc = fail(ctx, VR_ERR_HIP, "event time failed");
-            if (rep > 0 && ms < fastest) fastest = ms;
+        double fastest = 1.0e300;
+        for (int rep = 0; rep < 3 && rc == VR_OK; rep++) {      // the first run also warms the caches (and is the fast mode's probe)
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int k = 0; k < kRun && rc == VR_OK; k++)
+                rc = render_impl(ctx, width, height, 0, 0, width, height, part, parts, scratch[k & 1], 1, nullptr);
+            if (rc == VR_OK) rc = vr_synchronize(ctx);
+            const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (rep > 0 && s < fastest) fastest = s;
         }
         if (rc != VR_OK) break;
-        if (fastest < best_ms) {
-            best_ms = fastest;
+        if (fastest < best_s) {
+            best_s = fastest;
             best = budget;
         }
     }
     ctx->lane_budget = rc == VR_OK ? best : before;
     ctx->mode = mode;
-    ctx->pipeline_depth = depth;
-    (void)hipFree(scratch);
+    drain(ctx);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(scratch[0]);
+    (void)hipFree(scratch[1]);
     if (rc == VR_OK && chosen_budget) *chosen_budget = best;
     return rc;
 }
