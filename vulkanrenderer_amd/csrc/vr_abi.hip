@@ -91,7 +91,7 @@ struct vr_ctx {
     size_t frame_cap = 0;
     float *partial = nullptr;          // device staging for host-pointer partial renders
     size_t partial_cap = 0;
-    uint32_t *queue = nullptr;         // pixels the fast march hands to the reference-order march
+    vr::ReplayRay *queue = nullptr;    // rays the fast march hands to the reference-order march
     size_t queue_cap = 0;
     vr::LongRay *long_queue = nullptr; // rays the lane march hands to the wave march
     // Two frames in flight (vr_set_pipeline): fast frames alternate between the buffers above and this
@@ -109,7 +109,7 @@ struct vr_ctx {
     int last_set = -1;
     uint64_t pipe_index = 0;
     vr::Counters *counters_alt = nullptr;
-    uint32_t *queue_alt = nullptr;
+    vr::ReplayRay *queue_alt = nullptr;
     vr::LongRay *long_alt = nullptr;
     size_t alt_queue_cap = 0;
     uint2 *tiles_alt = nullptr;
@@ -133,7 +133,7 @@ constexpr size_t align_up(size_t n) { return (n + 255) & ~(size_t)255; }
 constexpr size_t kCountersAt = 0;
 constexpr size_t kTilesAt = kCountersAt + align_up(sizeof(vr::Counters));
 constexpr size_t kQueueAt = kTilesAt + align_up(kMaxTiles * sizeof(uint2));
-constexpr size_t kLongAt = kQueueAt + align_up(kMaxPixels * sizeof(uint32_t));
+constexpr size_t kLongAt = kQueueAt + align_up(kMaxPixels * sizeof(vr::ReplayRay));
 constexpr size_t kBytes = kLongAt + align_up(kMaxPixels * sizeof(vr::LongRay));
 constexpr int kMaxDevices = 64;
 }  // namespace static_scratch
@@ -415,7 +415,7 @@ int rows_of_part(int rows, int part, int parts)
 
 struct FrameBuffers {
     vr::Counters *counters;
-    uint32_t *queue;
+    vr::ReplayRay *queue;
     vr::LongRay *long_queue;
     uint2 *tiles;
     hipStream_t tail;        // stream of the kernels that finish the frame
@@ -1013,7 +1013,7 @@ static int render_impl(vr_ctx *ctx, int width, int height, int x0, int y0, int x
         ctx->queue = nullptr;
         ctx->long_queue = nullptr;
         ctx->queue_cap = 0;
-        VR_HIP(ctx, hipMalloc(&ctx->queue, pixels * sizeof(uint32_t)));
+        VR_HIP(ctx, hipMalloc(&ctx->queue, pixels * sizeof(vr::ReplayRay)));
         VR_HIP(ctx, hipMalloc(&ctx->long_queue, pixels * sizeof(vr::LongRay)));
         ctx->queue_cap = pixels;
     }
@@ -1035,7 +1035,7 @@ static int render_impl(vr_ctx *ctx, int width, int height, int x0, int y0, int x
     FrameBuffers fb{ctx->counters, ctx->queue, ctx->long_queue, ctx->tiles, ctx->stream, nullptr};
     if (use_static)
         fb = FrameBuffers{reinterpret_cast<vr::Counters *>(sp + static_scratch::kCountersAt),
-                          reinterpret_cast<uint32_t *>(sp + static_scratch::kQueueAt),
+                          reinterpret_cast<vr::ReplayRay *>(sp + static_scratch::kQueueAt),
                           reinterpret_cast<vr::LongRay *>(sp + static_scratch::kLongAt),
                           reinterpret_cast<uint2 *>(sp + static_scratch::kTilesAt), ctx->stream, nullptr};
     int set = 0;
@@ -1052,7 +1052,7 @@ static int render_impl(vr_ctx *ctx, int width, int height, int x0, int y0, int x
                 if (ctx->tiles_alt) (void)hipFree(ctx->tiles_alt);
                 ctx->queue_alt = nullptr; ctx->long_alt = nullptr; ctx->tiles_alt = nullptr;
                 ctx->alt_queue_cap = ctx->alt_tiles_cap = 0;
-                VR_HIP(ctx, hipMalloc(&ctx->queue_alt, pixels * sizeof(uint32_t)));
+                VR_HIP(ctx, hipMalloc(&ctx->queue_alt, pixels * sizeof(vr::ReplayRay)));
                 VR_HIP(ctx, hipMalloc(&ctx->long_alt, pixels * sizeof(vr::LongRay)));
                 VR_HIP(ctx, hipMalloc(&ctx->tiles_alt, tile_count * sizeof(uint2)));
                 ctx->alt_queue_cap = pixels;
@@ -1414,7 +1414,7 @@ int vr_render_partial(vr_ctx *ctx, int width, int height, float *out, int out_is
         ctx->queue = nullptr;
         ctx->long_queue = nullptr;
         ctx->queue_cap = 0;
-        VR_HIP(ctx, hipMalloc(&ctx->queue, pixels * sizeof(uint32_t)));
+        VR_HIP(ctx, hipMalloc(&ctx->queue, pixels * sizeof(vr::ReplayRay)));
         VR_HIP(ctx, hipMalloc(&ctx->long_queue, pixels * sizeof(vr::LongRay)));
         ctx->queue_cap = pixels;
     }

@@ -820,7 +820,7 @@ template <typename T, bool STATS, bool PARTIAL = false, bool SHADE = false>
 __device__ __forceinline__ void replay_ray(const VolumeView &vol, const FrameParams &fp, const float4 *s_lut,
                                            const Decider &dec, uint32_t *__restrict__ out, Counters *ctr,
                                            uint32_t *touched, uint32_t out_index, const uint2 *__restrict__ tiles,
-                                           int tiles_x, const float *carried = nullptr, float *result = nullptr)
+                                           int tiles_x, const float *carried = nullptr, float *result = nullptr, int dark_from = 0)
 {
     const int lane = threadIdx.x & 63;
     int px, py;
@@ -830,9 +830,11 @@ __device__ __forceinline__ void replay_ray(const VolumeView &vol, const FramePar
     const float step = (r.tmax - r.tmin) / (float)(uint32_t)last;
     unsigned long long evaluated = 0;
 
-    // from the eye: where does the ray go dark?
-    int start = 0;
-    if (dec.ok && r.hit) {
+    // Where does the ray go dark, seen from the eye?  The marches that queue a ray know: they hand over the
+    // first tap they did not visit once the transmittance of the visited ones is below kReplayDark (0: the
+    // ray never went dark, fold all of it).  A box of a split volume looks for the point among its own taps.
+    int start = (!PARTIAL && dec.ok && r.hit && dark_from > 0) ? (dark_from < last ? dark_from : last) : 0;
+    if (PARTIAL && dec.ok && r.hit) {
         RayModel fm = ray_model(r, vol, step, -1.0f);
         clip_to_tile(fm, r, step, tiles, tiles_x, px, py, ctr);
         double tr = 1.0;
@@ -963,6 +965,14 @@ __device__ __forceinline__ void replay_ray(const VolumeView &vol, const FramePar
     }
 }
 
+// A ray neither march could decide, queued for the reference-order replay: its pixel and, when the ray went
+// dark (transmittance of the taps visited below kReplayDark), the tap from which the replay has to fold:
+// every tap in front of `dark_from` was visited.  0: the ray reached the back without going dark.
+struct ReplayRay {
+    uint32_t pixel_id;
+    int dark_from;
+};
+
 // A ray the lane-per-ray march hands over to a whole wave: where it stands and what it has
 // accumulated (k_march_fast -> k_march_long).
 struct LongRay {
@@ -1064,7 +1074,7 @@ __device__ __forceinline__ void finish_partial(const VolumeView &vol, const Ray 
 template <typename T, bool STATS, bool PARTIAL, bool SHADE = false>
 __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FrameParams &fp, const float4 *s_lut,
                                             const Decider &dec, uint32_t *__restrict__ out, Counters *ctr,
-                                            uint32_t *touched, uint32_t *__restrict__ queue,
+                                            uint32_t *touched, ReplayRay *__restrict__ queue,
                                             LongRay *__restrict__ next_queue, unsigned int *next_count, int budget,
                                             bool in_rect, int px, int py, uint32_t pixel_id, float *__restrict__ partial_out,
                                             const uint2 *__restrict__ tiles, int tiles_x)
@@ -1098,7 +1108,7 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
     int t = last < rm.t_first ? last : rm.t_first;   // front-most tap that can matter
     const int t_stop = rm.t_stop;       // taps below it (the back tap aside) cannot matter either
     bool marching = in_rect && r.hit;   // still has taps with index >= 1 to visit
-    bool decided = false;
+    bool decided = false, gave_up = false;
     uint32_t rgba = 0xff000000u;        // miss: clear colour (VolumeRendering.comp:174,180)
     unsigned long long evaluated = 0, lookups = 0;
 
@@ -1320,6 +1330,11 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
             if (try_decide(t + 1)) {     // taps t .. 0 are still to come
                 decided = true;
                 marching = false;
+            } else if (Tr < kReplayDark) {
+                // dark and still on a rounding boundary: nothing behind can decide it any more (the interval
+                // is as narrow as the rounding bound allows); the replay folds it from here to the front
+                gave_up = true;
+                marching = false;
             }
         }
 #ifdef VR_DIAG
@@ -1342,7 +1357,9 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
             else o[0] = o[1] = o[2] = o[3] = o[4] = 0.0f;
         }
     } else if (in_rect) {
-        if (r.hit && !decided) {
+        if (r.hit && gave_up) {
+            queue[atomicAdd(&ctr->replay_count, 1u)] = ReplayRay{pixel_id, t + 1};
+        } else if (r.hit && !decided) {
             // back-most tap: its colour enters unweighted by its alpha (VolumeRendering.comp:189-191)
             const Tap p = tap_position(r, vol, step, 0);
             const Cell c = tap_cell(p, vol);
@@ -1364,7 +1381,7 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
             } else {
                 decided = fast_ok && try_decide(0);
             }
-            if (!decided) queue[atomicAdd(&ctr->replay_count, 1u)] = pixel_id;
+            if (!decided) queue[atomicAdd(&ctr->replay_count, 1u)] = ReplayRay{pixel_id, 0};
         }
         if (!r.hit || decided) out[pixel_id] = rgba;
     }
@@ -1410,7 +1427,7 @@ template <typename T, bool STATS, bool SHADE>
 __global__ __launch_bounds__(256, (STATS || SHADE) ? 1 : VR_FAST_MIN_WAVES) void k_march_fast(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
                                                    float4 border, const LutInfo *__restrict__ info,
                                                    uint32_t *__restrict__ out, Counters *ctr, uint32_t *touched,
-                                                   uint32_t *__restrict__ queue, LongRay *__restrict__ long_queue, int budget,
+                                                   ReplayRay *__restrict__ queue, LongRay *__restrict__ long_queue, int budget,
                                                    const uint2 *__restrict__ tiles, int tiles_x)
 {
     __shared__ float4 s_lut[kLutLds];
@@ -1472,7 +1489,7 @@ constexpr int kLongTaps = VR_LONG_TAPS;   // consecutive taps per lane and round
 template <typename T, int G, bool STATS, bool PARTIAL = false, bool SHADE = false>
 __device__ __forceinline__ bool continue_ray(const VolumeView &vol, const FrameParams &fp, const float4 *s_lut,
                                              const Decider &dec, Counters *ctr, uint32_t *touched, const LongRay &e, bool valid,
-                                             uint32_t &rgba, float *__restrict__ partial_out = nullptr)
+                                             uint32_t &rgba, int &dark_from, float *__restrict__ partial_out = nullptr)
 {
     static_assert(G == 16 || G == 32 || G == 64, "a group is a wave, a half or a quarter of one");
     const int lane = threadIdx.x & 63;
@@ -1497,6 +1514,7 @@ __device__ __forceinline__ bool continue_ray(const VolumeView &vol, const FrameP
     int t = e.t;
     bool decided = false;
     rgba = 0xff000000u;
+    dark_from = 0;
     unsigned long long evaluated = 0;
     // the back-most tap is needed when the march ends undecided: requested together with the last round's taps
     const Tap back_p = tap_position(r, vol, step, 0);
@@ -1612,7 +1630,13 @@ __device__ __forceinline__ bool continue_ray(const VolumeView &vol, const FrameP
 #pragma unroll
         for (int k = 0; k < kLongTaps; k++) cur[k] = nxt[k];
         cur_t = t;
-        if (!PARTIAL && dec.ok && Tr < (double)dec.tr_gate) decided = dec.decide(F0, F1, F2, Tr, S, (t > 0 ? t : 0) + 1, rgba);
+        if (!PARTIAL && dec.ok && Tr < (double)dec.tr_gate) {
+            decided = dec.decide(F0, F1, F2, Tr, S, (t > 0 ? t : 0) + 1, rgba);
+            if (!decided && Tr < kReplayDark) {
+                dark_from = t + 1;     // dark and still on a rounding boundary: the replay folds it from here
+                break;
+            }
+        }
     }
     if (PARTIAL) {
         float res[kPartial];
@@ -1623,7 +1647,7 @@ __device__ __forceinline__ bool continue_ray(const VolumeView &vol, const FrameP
         }
         return false;
     }
-    if (valid && !decided) {
+    if (valid && !decided && dark_from == 0) {
         // back-most tap: its colour enters unweighted by its alpha (VolumeRendering.comp:189-191)
         if (!back_requested) back_raw = fetch_volume<T>(back_c, back_brick, vol);
         const float4 tf = sample_tf(s_lut, filter_volume<T>(back_raw, back_c, vol));
@@ -1687,7 +1711,7 @@ template <typename T, int G, bool STATS, bool SHADE>
 __global__ __launch_bounds__(256, (STATS || SHADE) ? 1 : VR_LONG_MIN_WAVES) void k_march_long(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
                                                    float4 border, const LutInfo *__restrict__ info,
                                                    uint32_t *__restrict__ out, Counters *ctr, uint32_t *touched,
-                                                   uint32_t *__restrict__ queue, const LongRay *__restrict__ long_queue)
+                                                   ReplayRay *__restrict__ queue, const LongRay *__restrict__ long_queue)
 {
     __shared__ float4 s_lut[kLutLds];
     stage_lut(s_lut, lut, border);
@@ -1698,10 +1722,11 @@ __global__ __launch_bounds__(256, (STATS || SHADE) ? 1 : VR_LONG_MIN_WAVES) void
     for_queue_entries<64 / G>(entries, [&](uint32_t entry, bool valid) {
         const LongRay e = long_queue[entry];
         uint32_t rgba;
-        const bool decided = continue_ray<T, G, STATS, false, SHADE>(vol, fp, s_lut, dec, ctr, touched, e, valid, rgba);
+        int dark_from;
+        const bool decided = continue_ray<T, G, STATS, false, SHADE>(vol, fp, s_lut, dec, ctr, touched, e, valid, rgba, dark_from);
         if (valid && sub == 0) {
             if (decided) out[e.pixel_id] = rgba;
-            else queue[atomicAdd(&ctr->replay_count, 1u)] = e.pixel_id;
+            else queue[atomicAdd(&ctr->replay_count, 1u)] = ReplayRay{e.pixel_id, dark_from};
         }
     });
 }
@@ -1711,14 +1736,17 @@ template <typename T, bool STATS, bool SHADE>
 __global__ __launch_bounds__(256) void k_replay_exact(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
                                                      float4 border, const LutInfo *__restrict__ info,
                                                      uint32_t *__restrict__ out, Counters *ctr, uint32_t *touched,
-                                                     const uint32_t *__restrict__ queue, const uint2 *__restrict__ tiles,
+                                                     const ReplayRay *__restrict__ queue, const uint2 *__restrict__ tiles,
                                                      int tiles_x)
 {
     __shared__ float4 s_lut[kLutLds];
     stage_lut(s_lut, lut, border);
     const Decider dec(info);
     for_queue_entries<1>(ctr->replay_count, [&](uint32_t entry, bool valid) {
-        if (valid) replay_ray<T, STATS, false, SHADE>(vol, fp, s_lut, dec, out, ctr, touched, queue[entry], tiles, tiles_x);
+        if (valid) {
+            const ReplayRay e = queue[entry];
+            replay_ray<T, STATS, false, SHADE>(vol, fp, s_lut, dec, out, ctr, touched, e.pixel_id, tiles, tiles_x, nullptr, nullptr, e.dark_from);
+        }
     });
 }
 

@@ -98,7 +98,8 @@ __global__ __launch_bounds__(256) void k_partial_long(VolumeView vol, FrameParam
     for_queue_entries<1>(ctr->long_count, [&](uint32_t entry, bool valid) {
         const LongRay e = long_queue[entry];
         uint32_t rgba;
-        continue_ray<T, 64, false, true>(vol, fp, s_lut, dec, ctr, nullptr, e, valid, rgba, out);
+        int dark_from;
+        continue_ray<T, 64, false, true>(vol, fp, s_lut, dec, ctr, nullptr, e, valid, rgba, dark_from, out);
     });
 }
 
