@@ -928,23 +928,34 @@ __device__ __forceinline__ void replay_ray(const VolumeView &vol, const FramePar
                 tf.x += sh; tf.y += sh; tf.z += sh;
             }
             unsigned long long todo = __ballot(fetch && (t == 0 || !identity));
+            // each lane forms its tap's products once; the fold then reads them lane after lane.  The lane
+            // index is the same in all lanes (it comes from the ballot), so the reads are scalar broadcasts.
+            const float ia = 1.0f - tf.w;
+            const float ax = tf.w * tf.x, ay = tf.w * tf.y, az = tf.w * tf.z;
+            auto from_lane = [](float v, int lane_index) -> float {
+                return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_index));
+            };
+            const bool both = start > 0;     // folding from the back, the two bounds are one value
             while (todo) {
                 const int src = __builtin_ctzll(todo);
                 todo &= todo - 1;
-                const float a = __shfl(tf.w, src), x = __shfl(tf.x, src), y = __shfl(tf.y, src), z = __shfl(tf.z, src);
                 if (base + src == 0) {
-                    lo[0] = hi[0] = x; lo[1] = hi[1] = y; lo[2] = hi[2] = z;
+                    lo[0] = hi[0] = from_lane(tf.x, src);
+                    lo[1] = hi[1] = from_lane(tf.y, src);
+                    lo[2] = hi[2] = from_lane(tf.z, src);
                 } else {
-                    const float ia = 1.0f - a;
-                    const float ax = a * x, ay = a * y, az = a * z;
-                    lo[0] = ax + ia * lo[0];
-                    lo[1] = ay + ia * lo[1];
-                    lo[2] = az + ia * lo[2];
-                    hi[0] = ax + ia * hi[0];
-                    hi[1] = ay + ia * hi[1];
-                    hi[2] = az + ia * hi[2];
+                    const float sia = from_lane(ia, src), sx = from_lane(ax, src), sy = from_lane(ay, src), sz = from_lane(az, src);
+                    lo[0] = sx + sia * lo[0];
+                    lo[1] = sy + sia * lo[1];
+                    lo[2] = sz + sia * lo[2];
+                    if (both) {
+                        hi[0] = sx + sia * hi[0];
+                        hi[1] = sy + sia * hi[1];
+                        hi[2] = sz + sia * hi[2];
+                    }
                 }
             }
+            if (!both) { hi[0] = lo[0]; hi[1] = lo[1]; hi[2] = lo[2]; }
             base += 64;
         }
         const bool met = __float_as_uint(lo[0]) == __float_as_uint(hi[0]) && __float_as_uint(lo[1]) == __float_as_uint(hi[1]) &&
