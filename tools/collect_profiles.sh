@@ -20,6 +20,7 @@ pass write WRITE_SIZE
 pass tcc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum
 cd "$root"
 python3 tools/pmc_summary.py "$out/sq1" "$out/sq2" "$out/fetch" "$out/write" "$out/tcc" > "$out/pmc_summary.txt"
+# afterwards, in the repository: python tools/make_traffic_json.py gpurun_out/prof_$tag 2048_3840x2160_fast profiles/$tag
 cp "$out"/bench/*/bench_kernel_stats.csv "$out/bench_kernel_stats.csv" 2>/dev/null || cp "$out"/bench/bench_kernel_stats.csv "$out/bench_kernel_stats.csv"
 tail -1 "$out/bench_under_rocprof.json"
 cat "$out/pmc_summary.txt"

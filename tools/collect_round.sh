@@ -1,0 +1,22 @@
+#!/bin/bash
+# Everything the round's measurements in DESIGN.md / profiles/ come from, on the GPU box:
+# usage: bash tools/collect_round.sh <tag>   -> gpurun_out/round_<tag>/ and gpurun_out/prof_<tag>/
+set -u
+tag=${1:-rX}
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+out=$root/gpurun_out/round_$tag
+mkdir -p "$out"
+cd "$root"
+bash tools/collect_profiles.sh "$tag" > "$out/collect_profiles.log" 2>&1 || { tail -5 "$out/collect_profiles.log"; exit 1; }
+timeout -k 10 400 python3 bench.py > "$out/bench_c4.json" 2> "$out/bench_c4.err" || exit 1
+for c in c1 c2 c3 c5; do
+  timeout -k 10 300 python3 bench.py --config $c --no-cpu-baseline > "$out/bench_$c.json" 2> "$out/bench_$c.err" || exit 1
+done
+timeout -k 10 300 python3 bench.py --config c2 --table translucent --steps 60 --no-cpu-baseline > "$out/bench_c2_translucent.json" 2> "$out/bench_c2_translucent.err" || exit 1
+timeout -k 10 300 python3 bench.py --shading --no-cpu-baseline --steps 120 > "$out/bench_c4_shaded.json" 2> "$out/bench_c4_shaded.err" || exit 1
+timeout -k 10 300 python3 tools/band_times.py > "$out/band_times.txt" 2>&1 || exit 1
+for p in 8; do bash tools/share_profile.sh $p > "$out/share_$p.txt" 2>&1 || exit 1; done
+bash tools/small_config_profile.sh > "$out/small_configs.txt" 2>&1 || exit 1
+timeout -k 10 200 python3 tools/frame_stats.py > "$out/frame_stats.txt" 2>&1 || exit 1
+timeout -k 10 200 python3 tools/translucent.py > "$out/translucent.txt" 2>&1 || exit 1
+echo done

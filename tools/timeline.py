@@ -67,10 +67,12 @@ print("per wave: rounds mean %.1f p90 %.0f max %.0f | max-lane model iters mean 
 busy = rounds > 0
 print("waves with rounds:", int(busy.sum()), "their dur mean %.1f us, rounds mean %.1f, both mean %.1f" % (dur[busy].mean(), rounds[busy].mean(), mboth[busy].mean()))
 print("waves without rounds: dur mean %.1f us, both mean %.1f" % (dur[~busy].mean(), mboth[~busy].mean()))
-wave_passes = (t[:, 2] & 0xffffffff).astype(np.float64)
+wave_passes = (t[:, 2] & 0xffff).astype(np.float64)
+first_passes = ((t[:, 2] >> 16) & 0xffff).astype(np.float64)
 lane_passes = (t[:, 2] >> 32).astype(np.float64)
 print("passes of the skipping loop the WAVE executed: mean %.1f (busy waves %.1f, p90 %.0f); lanes active in a pass: %.1f of 64" % (
     wave_passes.mean(), wave_passes[busy].mean(), np.percentile(wave_passes[busy], 90), lane_passes.sum() / max(1.0, wave_passes.sum())))
+print("of them before the first fetch round (busy waves): %.1f" % first_passes[busy].mean())
 for lo, hi in ((1, 8), (8, 16), (16, 32), (32, 64), (64, 128), (128, 1e9)):
     sel = busy & (rounds >= lo) & (rounds < hi)
     if sel.any():

@@ -112,8 +112,15 @@ struct vr_ctx {
     vr::ReplayRay *queue_alt = nullptr;
     vr::LongRay *long_alt = nullptr;
     size_t alt_queue_cap = 0;
-    uint2 *tiles_alt = nullptr;
-    size_t alt_tiles_cap = 0;
+    // Two frames in flight: the per-tile depth ranges of a frame depend on the camera alone, so they are
+    // built on a third stream while the previous frame is still marching; three range buffers in turn, as a
+    // buffer is read until its frame's replay has finished (two frames later at most).
+    hipStream_t prep_stream = nullptr;
+    uint2 *tiles_ring[3] = {nullptr, nullptr, nullptr};
+    size_t tiles_ring_cap = 0;
+    hipEvent_t ranges_done[3] = {nullptr, nullptr, nullptr}, ranges_free[3] = {nullptr, nullptr, nullptr};
+    bool ranges_busy[3] = {false, false, false};
+    uint64_t ring_index = 0;
     // test hook (VR_TEST_FAIL_ALLOC=n at vr_create): the n-th device allocation of a volume upload
     // fails, so that the error path of the upload can be exercised without exhausting the GPU
     int fail_alloc_in = 0;
@@ -132,7 +139,7 @@ constexpr size_t kMaxTiles = 2 * kMaxPixels / 64;           // 8x8-pixel tiles; 
 constexpr size_t align_up(size_t n) { return (n + 255) & ~(size_t)255; }
 constexpr size_t kCountersAt = 0;
 constexpr size_t kTilesAt = kCountersAt + align_up(sizeof(vr::Counters));
-constexpr size_t kQueueAt = kTilesAt + align_up(kMaxTiles * sizeof(uint2));
+constexpr size_t kQueueAt = kTilesAt + align_up((kMaxTiles + 1) * sizeof(uint2));
 constexpr size_t kLongAt = kQueueAt + align_up(kMaxPixels * sizeof(vr::ReplayRay));
 constexpr size_t kBytes = kLongAt + align_up(kMaxPixels * sizeof(vr::LongRay));
 constexpr int kMaxDevices = 64;
@@ -420,6 +427,9 @@ struct FrameBuffers {
     uint2 *tiles;
     hipStream_t tail;        // stream of the kernels that finish the frame
     hipEvent_t main_done;    // recorded after the lane march when the tail runs on another stream, else null
+    hipStream_t prep;        // stream the depth ranges are built on when it is not the main one, else null
+    hipEvent_t ranges_done;  // recorded on `prep` after the ranges are built
+    hipEvent_t ranges_free;  // to wait for on `prep` before the range buffer is overwritten, or null
 };
 
 // The lane budget when neither vr_tune nor the environment has set one.  The lane march is one wave per
@@ -464,9 +474,15 @@ void launch_frame_as(vr_ctx *ctx, const vr::FrameParams &fp, uint32_t *d_out, co
         const int tiles_x = (fp.width + tile_px - 1) / tile_px, tiles_y = (fp.height + tile_px - 1) / tile_px;
         const uint2 *tiles = nullptr;
         if (ctx->tile_clip && fb.tiles && ctx->occ_count > 0) {
-            (void)hipMemsetAsync(fb.tiles, 0, (size_t)tiles_x * tiles_y * sizeof(uint2), s);
-            hipLaunchKernelGGL(vr::k_splat_bricks, dim3((ctx->occ_count + 255) / 256), dim3(256), 0, s, vol, fp, ctx->occ_list, ctx->occ_count,
+            hipStream_t ps = fb.prep ? fb.prep : s;
+            if (fb.prep && fb.ranges_free) (void)hipStreamWaitEvent(ps, fb.ranges_free, 0);
+            (void)hipMemsetAsync(fb.tiles, 0, ((size_t)tiles_x * tiles_y + 1) * sizeof(uint2), ps);   // + the word that switches the ranges off
+            hipLaunchKernelGGL(vr::k_splat_bricks, dim3((ctx->occ_count + 255) / 256), dim3(256), 0, ps, vol, fp, ctx->occ_list, ctx->occ_count,
                                fb.tiles, tiles_x, tiles_y, fb.counters);
+            if (fb.prep) {
+                (void)hipEventRecord(fb.ranges_done, ps);
+                (void)hipStreamWaitEvent(s, fb.ranges_done, 0);
+            }
             tiles = fb.tiles;
             (void)hipEventRecord(ctx->ring_a[slot], s);   // the ring times the march kernel alone
         }
@@ -559,6 +575,7 @@ int vr_destroy(vr_ctx *ctx)
 {
     if (!ctx) return VR_OK;
     (void)hipSetDevice(ctx->device);
+    if (ctx->prep_stream) (void)hipStreamSynchronize(ctx->prep_stream);
     if (ctx->tail_stream) (void)hipStreamSynchronize(ctx->tail_stream);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     ctx->tail_busy[0] = ctx->tail_busy[1] = false;
@@ -566,7 +583,12 @@ int vr_destroy(vr_ctx *ctx)
     if (ctx->counters_alt) (void)hipFree(ctx->counters_alt);
     if (ctx->queue_alt) (void)hipFree(ctx->queue_alt);
     if (ctx->long_alt) (void)hipFree(ctx->long_alt);
-    if (ctx->tiles_alt) (void)hipFree(ctx->tiles_alt);
+    for (int k = 0; k < 3; k++) {
+        if (ctx->tiles_ring[k]) (void)hipFree(ctx->tiles_ring[k]);
+        if (ctx->ranges_done[k]) (void)hipEventDestroy(ctx->ranges_done[k]);
+        if (ctx->ranges_free[k]) (void)hipEventDestroy(ctx->ranges_free[k]);
+    }
+    if (ctx->prep_stream) (void)hipStreamDestroy(ctx->prep_stream);
     for (int k = 0; k < 2; k++) {
         if (ctx->main_done[k]) (void)hipEventDestroy(ctx->main_done[k]);
         if (ctx->tail_done[k]) (void)hipEventDestroy(ctx->tail_done[k]);
@@ -620,6 +642,11 @@ int vr_set_pipeline(vr_ctx *ctx, int frames_in_flight)
             VR_HIP(ctx, hipEventCreateWithFlags(&ctx->main_done[k], hipEventDisableTiming));
             VR_HIP(ctx, hipEventCreateWithFlags(&ctx->tail_done[k], hipEventDisableTiming));
         }
+        for (int k = 0; k < 3; k++) {
+            VR_HIP(ctx, hipEventCreateWithFlags(&ctx->ranges_done[k], hipEventDisableTiming));
+            VR_HIP(ctx, hipEventCreateWithFlags(&ctx->ranges_free[k], hipEventDisableTiming));
+        }
+        VR_HIP(ctx, hipStreamCreateWithFlags(&ctx->prep_stream, hipStreamNonBlocking));
         VR_HIP(ctx, hipMalloc(&ctx->counters_alt, sizeof(vr::Counters)));
         VR_HIP(ctx, hipMemsetAsync(ctx->counters_alt, 0, sizeof(vr::Counters), ctx->stream));
         // The finishing kernels are short chains of dependent steps and may be given their few waves first
@@ -1024,7 +1051,7 @@ static int render_impl(vr_ctx *ctx, int width, int height, int x0, int y0, int x
             if (ctx->tiles) (void)hipFree(ctx->tiles);
             ctx->tiles = nullptr;
             ctx->tiles_cap = 0;
-            VR_HIP(ctx, hipMalloc(&ctx->tiles, tile_count * sizeof(uint2)));
+            VR_HIP(ctx, hipMalloc(&ctx->tiles, (tile_count + 1) * sizeof(uint2)));
             ctx->tiles_cap = tile_count;
         }
     }
@@ -1032,34 +1059,42 @@ static int render_impl(vr_ctx *ctx, int width, int height, int x0, int y0, int x
     // frame first lets the frames in flight finish and then runs on the one stream.
     const bool piped = fast && out_is_device && !want_stats && ctx->pipeline_depth == 2 && !use_static;
     if (!piped) drain(ctx);
-    FrameBuffers fb{ctx->counters, ctx->queue, ctx->long_queue, ctx->tiles, ctx->stream, nullptr};
+    FrameBuffers fb{ctx->counters, ctx->queue, ctx->long_queue, ctx->tiles, ctx->stream, nullptr, nullptr, nullptr, nullptr};
     if (use_static)
         fb = FrameBuffers{reinterpret_cast<vr::Counters *>(sp + static_scratch::kCountersAt),
                           reinterpret_cast<vr::ReplayRay *>(sp + static_scratch::kQueueAt),
                           reinterpret_cast<vr::LongRay *>(sp + static_scratch::kLongAt),
-                          reinterpret_cast<uint2 *>(sp + static_scratch::kTilesAt), ctx->stream, nullptr};
-    int set = 0;
+                          reinterpret_cast<uint2 *>(sp + static_scratch::kTilesAt), ctx->stream, nullptr, nullptr, nullptr, nullptr};
+    int set = 0, ring = -1;
     if (piped) {
         set = (int)(ctx->pipe_index++ & 1u);
-        if (set == 1) {
-            const int tile_px = 1 << vr::kRangeShift;
-            const size_t tile_count = (size_t)((width + tile_px - 1) / tile_px) * (size_t)((height + tile_px - 1) / tile_px);
-            if (pixels > ctx->alt_queue_cap || tile_count > ctx->alt_tiles_cap) {
-                drain(ctx);
-                VR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                if (ctx->queue_alt) (void)hipFree(ctx->queue_alt);
-                if (ctx->long_alt) (void)hipFree(ctx->long_alt);
-                if (ctx->tiles_alt) (void)hipFree(ctx->tiles_alt);
-                ctx->queue_alt = nullptr; ctx->long_alt = nullptr; ctx->tiles_alt = nullptr;
-                ctx->alt_queue_cap = ctx->alt_tiles_cap = 0;
-                VR_HIP(ctx, hipMalloc(&ctx->queue_alt, pixels * sizeof(vr::ReplayRay)));
-                VR_HIP(ctx, hipMalloc(&ctx->long_alt, pixels * sizeof(vr::LongRay)));
-                VR_HIP(ctx, hipMalloc(&ctx->tiles_alt, tile_count * sizeof(uint2)));
-                ctx->alt_queue_cap = pixels;
-                ctx->alt_tiles_cap = tile_count;
+        const int tile_px = 1 << vr::kRangeShift;
+        const size_t tile_count = (size_t)((width + tile_px - 1) / tile_px) * (size_t)((height + tile_px - 1) / tile_px);
+        if (pixels > ctx->alt_queue_cap || tile_count > ctx->tiles_ring_cap) {
+            drain(ctx);
+            VR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->queue_alt) (void)hipFree(ctx->queue_alt);
+            if (ctx->long_alt) (void)hipFree(ctx->long_alt);
+            ctx->queue_alt = nullptr; ctx->long_alt = nullptr;
+            ctx->alt_queue_cap = 0;
+            for (int k = 0; k < 3; k++) {
+                if (ctx->tiles_ring[k]) (void)hipFree(ctx->tiles_ring[k]);
+                ctx->tiles_ring[k] = nullptr;
+                ctx->ranges_busy[k] = false;
             }
-            fb = FrameBuffers{ctx->counters_alt, ctx->queue_alt, ctx->long_alt, ctx->tiles_alt, ctx->stream, nullptr};
+            ctx->tiles_ring_cap = 0;
+            VR_HIP(ctx, hipMalloc(&ctx->queue_alt, pixels * sizeof(vr::ReplayRay)));
+            VR_HIP(ctx, hipMalloc(&ctx->long_alt, pixels * sizeof(vr::LongRay)));
+            for (int k = 0; k < 3; k++) VR_HIP(ctx, hipMalloc(&ctx->tiles_ring[k], (tile_count + 1) * sizeof(uint2)));
+            ctx->alt_queue_cap = pixels;
+            ctx->tiles_ring_cap = tile_count;
         }
+        if (set == 1) fb = FrameBuffers{ctx->counters_alt, ctx->queue_alt, ctx->long_alt, nullptr, ctx->stream, nullptr, nullptr, nullptr, nullptr};
+        ring = (int)(ctx->ring_index++ % 3u);
+        fb.tiles = ctx->tiles_ring[ring];
+        fb.prep = ctx->prep_stream;
+        fb.ranges_done = ctx->ranges_done[ring];
+        fb.ranges_free = ctx->ranges_busy[ring] ? ctx->ranges_free[ring] : nullptr;
         // this set's buffers were last used by the frame before the previous one
         if (ctx->tail_busy[set]) {
             VR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->tail_done[set], 0));
@@ -1083,6 +1118,8 @@ static int render_impl(vr_ctx *ctx, int width, int height, int x0, int y0, int x
         VR_HIP(ctx, hipEventRecord(ctx->tail_done[set], ctx->tail_stream));
         ctx->tail_busy[set] = true;
         ctx->last_set = set;
+        VR_HIP(ctx, hipEventRecord(ctx->ranges_free[ring], ctx->tail_stream));   // the replay was the last reader of the ranges
+        ctx->ranges_busy[ring] = true;
     } else {
         ctx->last_set = -1;
     }
@@ -1433,12 +1470,12 @@ int vr_render_partial(vr_ctx *ctx, int width, int height, float *out, int out_is
         if (ctx->tiles) (void)hipFree(ctx->tiles);
         ctx->tiles = nullptr;
         ctx->tiles_cap = 0;
-        VR_HIP(ctx, hipMalloc(&ctx->tiles, tile_count * sizeof(uint2)));
+        VR_HIP(ctx, hipMalloc(&ctx->tiles, (tile_count + 1) * sizeof(uint2)));
         ctx->tiles_cap = tile_count;
     }
     const uint2 *range = nullptr;
     if (ctx->tile_clip && ctx->occ_count > 0) {
-        VR_HIP(ctx, hipMemsetAsync(ctx->tiles, 0, tile_count * sizeof(uint2), ctx->stream));
+        VR_HIP(ctx, hipMemsetAsync(ctx->tiles, 0, (tile_count + 1) * sizeof(uint2), ctx->stream));
         hipLaunchKernelGGL(vr::k_splat_bricks, dim3((ctx->occ_count + 255) / 256), dim3(256), 0, ctx->stream, vol, fp, ctx->occ_list,
                            ctx->occ_count, ctx->tiles, tiles_x, tiles_y, ctx->counters);
         range = ctx->tiles;

@@ -71,7 +71,7 @@ struct Counters {
     unsigned long long replay_rays;
     unsigned int replay_count;  // fast mode: rays queued for the reference-order replay
     unsigned int long_count;    // fast mode: rays handed from the lane march to the wave march
-    unsigned int clip_off;      // fast mode: the per-tile depth ranges could not be built for this camera
+    unsigned int pad1_;
     unsigned int pad0_;
     // counting builds only: where the taps of a fast frame are fetched
     unsigned long long long_samples;     // by the wave-per-ray continuation

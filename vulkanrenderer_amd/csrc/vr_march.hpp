@@ -407,6 +407,18 @@ __device__ __forceinline__ bool brick_is_empty(const VolumeView &vol, int bx, in
 
 constexpr uint32_t kSplatSlots = 1024, kNoTile = 0xffffffffu;
 
+// One word behind the tiles' ranges says that the ranges could not be built for this camera (a brick
+// behind or around the eye): the marches then take every ray's full tap range.  It travels with the
+// ranges because the pass that writes both may run ahead of the frame's other set-up, on a stream of its own.
+__device__ __forceinline__ size_t clip_flag_index(int tiles_x, int height)
+{
+    return (size_t)tiles_x * (size_t)((height + (1 << kRangeShift) - 1) >> kRangeShift);
+}
+__device__ __forceinline__ bool clip_disabled(const uint2 *__restrict__ tiles, int tiles_x, const FrameParams &fp)
+{
+    return tiles[clip_flag_index(tiles_x, fp.height)].x != 0u;
+}
+
 // Raises the range of one tile in global memory.  Both numbers only grow, so a range that would not
 // raise what the tile already holds has nothing to write; atomics on one address are served one
 // after the other.
@@ -476,7 +488,7 @@ __device__ __forceinline__ void splat_one(const VolumeView &vol, const FramePara
         pymin = fminf(pymin, py); pymax = fmaxf(pymax, py);
     }
     if (!ok) {
-        atomicOr(&ctr->clip_off, 1u);
+        atomicOr(&tiles[(size_t)tiles_x * tiles_y].x, 1u);
         return;
     }
     const float cx = 0.5f * (x0 + x1) - fp.loc[0], cy = 0.5f * (y0 + y1) - fp.loc[1], cz = 0.5f * (z0 + z1) - fp.loc[2];
@@ -487,7 +499,7 @@ __device__ __forceinline__ void splat_one(const VolumeView &vol, const FramePara
     const int ty0 = max(0, (int)floorf(pymin - 1.5f) >> kRangeShift), ty1 = min(tiles_y - 1, (int)floorf(pymax + 1.5f) >> kRangeShift);
     if (tx0 > tx1 || ty0 > ty1) return;   // off screen
     if ((tx1 - tx0 + 1) * (ty1 - ty0 + 1) > 4096) {   // eye very close to a brick: not worth the writes
-        atomicOr(&ctr->clip_off, 1u);
+        atomicOr(&tiles[(size_t)tiles_x * tiles_y].x, 1u);
         return;
     }
     const uint32_t nb = front ? 0x7f800000u - __float_as_uint(near) : 0u, fb = back ? __float_as_uint(far) : 0u;
@@ -545,9 +557,9 @@ __global__ __launch_bounds__(256) void k_splat_bricks(VolumeView vol, FrameParam
 
 // Narrows a ray's tap range to its tile's depth range.
 __device__ __forceinline__ void clip_to_tile(RayModel &m, const Ray &r, float step, const uint2 *__restrict__ tiles,
-                                             int tiles_x, int px, int py, const Counters *ctr)
+                                             int tiles_x, int px, int py, const FrameParams &fp)
 {
-    if (!tiles || ctr->clip_off || !(step > 0.0f)) return;
+    if (!tiles || clip_disabled(tiles, tiles_x, fp) || !(step > 0.0f)) return;
     const uint2 range = tiles[(size_t)(py >> kRangeShift) * tiles_x + (px >> kRangeShift)];
     if (range.y == 0u) {   // no occupied brick projects into this tile
         m.t_first = 0;
@@ -836,7 +848,7 @@ __device__ __forceinline__ void replay_ray(const VolumeView &vol, const FramePar
     int start = (!PARTIAL && dec.ok && r.hit && dark_from > 0) ? (dark_from < last ? dark_from : last) : 0;
     if (PARTIAL && dec.ok && r.hit) {
         RayModel fm = ray_model(r, vol, step, -1.0f);
-        clip_to_tile(fm, r, step, tiles, tiles_x, px, py, ctr);
+        clip_to_tile(fm, r, step, tiles, tiles_x, px, py, fp);
         double tr = 1.0;
         int t = last < fm.t_first ? last : fm.t_first;
         while (t >= fm.t_stop && !(tr < kReplayDark)) {
@@ -870,7 +882,7 @@ __device__ __forceinline__ void replay_ray(const VolumeView &vol, const FramePar
     }
 
     RayModel rm = ray_model(r, vol, step, 1.0f);
-    clip_to_tile(rm, r, step, tiles, tiles_x, px, py, ctr);
+    clip_to_tile(rm, r, step, tiles, tiles_x, px, py, fp);
     float lo[3] = {0.0f, 0.0f, 0.0f}, hi[3] = {0.0f, 0.0f, 0.0f};
     for (int attempt = 0; attempt < 2; attempt++) {
         if (start > 0) {
@@ -1092,7 +1104,7 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
 {
 #ifdef VR_DIAG
     const unsigned long long diag_t0 = wall_clock64();
-    unsigned int diag_model = 0, diag_exact = 0, diag_rounds = 0, diag_sampled = 0, diag_wave_passes = 0;
+    unsigned int diag_model = 0, diag_exact = 0, diag_rounds = 0, diag_sampled = 0, diag_wave_passes = 0, diag_wave_passes0 = 0;
     long long diag_c0 = clock64(), diag_setup = 0, diag_skip = 0, diag_sample = 0;
 #endif
     const Ray r = make_ray(fp, in_rect ? px : fp.x0, in_rect ? py : fp.y0);
@@ -1103,7 +1115,7 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
     RayModel rm;
     // more than half of the tiles of a typical frame have no occupied brick behind them: their rays need
     // no line model, only the back-most tap
-    const bool nothing = in_rect && tiles && !ctr->clip_off && step > 0.0f &&
+    const bool nothing = in_rect && tiles && !clip_disabled(tiles, tiles_x, fp) && step > 0.0f &&
                          tiles[(size_t)(py >> kRangeShift) * tiles_x + (px >> kRangeShift)].y == 0u;
     if (nothing) {
         rm = RayModel{};
@@ -1111,7 +1123,7 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
         rm.t_stop = 0x7fffffff;
     } else {
         rm = ray_model(r, vol, step, -1.0f);
-        if (in_rect) clip_to_tile(rm, r, step, tiles, tiles_x, px, py, ctr);
+        if (in_rect) clip_to_tile(rm, r, step, tiles, tiles_x, px, py, fp);
     }
 
     double F0 = 0.0, F1 = 0.0, F2 = 0.0, Tr = 1.0;
@@ -1188,7 +1200,10 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
             if (t < t_stop) { marching = false; break; }
             work++;
 #ifdef VR_DIAG
-            if ((int)(threadIdx.x & 63) == __builtin_ctzll(__ballot(true))) diag_wave_passes++;   // one lane counts for the wave
+            if ((int)(threadIdx.x & 63) == __builtin_ctzll(__ballot(true))) {   // one lane counts for the wave
+                diag_wave_passes++;
+                if (round == 0) diag_wave_passes0++;
+            }
 #endif
             // position of tap t in the padded texel grid for the span counts below: the line model's, or,
             // when every pass takes the exact position anyway, that one (it differs from the model by
@@ -1407,6 +1422,7 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
     unsigned int diag_both = diag_model + diag_exact, diag_sum = diag_sampled, diag_lane_passes = diag_model + diag_exact;
     for (int o = 32; o > 0; o >>= 1) {
         diag_wave_passes += (unsigned int)__shfl_xor((int)diag_wave_passes, o);
+        diag_wave_passes0 += (unsigned int)__shfl_xor((int)diag_wave_passes0, o);
         diag_lane_passes += (unsigned int)__shfl_xor((int)diag_lane_passes, o);
         diag_model = max(diag_model, (unsigned int)__shfl_xor((int)diag_model, o));
         diag_exact = max(diag_exact, (unsigned int)__shfl_xor((int)diag_exact, o));
@@ -1426,7 +1442,7 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
         g_vr_timeline[wave_id * 8 + 0] = diag_t0;
         g_vr_timeline[wave_id * 8 + 1] = wall_clock64();
         (void)hw; (void)xcc;
-        g_vr_timeline[wave_id * 8 + 2] = (unsigned long long)diag_wave_passes | ((unsigned long long)diag_lane_passes << 32);
+        g_vr_timeline[wave_id * 8 + 2] = (unsigned long long)diag_wave_passes | ((unsigned long long)diag_wave_passes0 << 16) | ((unsigned long long)diag_lane_passes << 32);
         g_vr_timeline[wave_id * 8 + 3] = (unsigned long long)diag_rounds | ((unsigned long long)diag_model << 12) |
                                          ((unsigned long long)diag_exact << 24) | ((unsigned long long)diag_both << 36) |
                                          ((unsigned long long)diag_sum << 48);
