@@ -95,9 +95,9 @@ __device__ __forceinline__ float lerp_fma(float w, float a, float b) { return __
 // like size (both neighbours are border texels either way); NaN behaves like -2.
 __device__ __forceinline__ int safe_index(float fl, int size)
 {
-    if (!(fl >= -2.0f)) fl = -2.0f;
-    if (fl > (float)size) fl = (float)size;
-    return (int)fl;
+    // one instruction: the median of (fl, -2, size) clamps, and with a NaN among its operands v_med3_f32
+    // returns their minimum taken NaN-free, i.e. -2
+    return (int)__builtin_amdgcn_fmed3f(fl, -2.0f, (float)size);
 }
 
 template <typename T>
