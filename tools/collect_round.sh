@@ -19,4 +19,5 @@ for p in 8; do bash tools/share_profile.sh $p > "$out/share_$p.txt" 2>&1 || exit
 bash tools/small_config_profile.sh > "$out/small_configs.txt" 2>&1 || exit 1
 timeout -k 10 200 python3 tools/frame_stats.py > "$out/frame_stats.txt" 2>&1 || exit 1
 timeout -k 10 200 python3 tools/translucent.py > "$out/translucent.txt" 2>&1 || exit 1
+for e in 2048 4096; do bash tools/sortlast_balance.sh $e "$out" > "$out/sortlast_balance_$e.txt" 2>&1 || exit 1; done
 echo done
