@@ -648,6 +648,40 @@ def test_sort_first_bands_tile_the_frame(ctx, vr, oracle, mode):
         assert np.array_equal(got, full), parts
 
 
+def test_tiles_in_order_of_their_time(ctx, vr, oracle):
+    """Frames rendered one at a time launch their tiles longest first, by the times the previous frame over
+    the same tiles noted (launches of 8192 tiles and more).  Any order gives the same bytes: a sequence of
+    views, a change of size in between, and the bands of a split, against the reference-order march with
+    skipping of the same context."""
+    ctx.upload_volume(oracle.phantom(64, np.uint16))
+    ctx.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+    ctx.set_sampling(150)
+    cams = [(math.radians(20.0 + 7.0 * k), math.radians(15.0 - 3.0 * k)) for k in range(4)]
+
+    def reference(w, h, cam):
+        ctx.set_mode(2)
+        ctx.set_camera(*cam)
+        img = ctx.render(w, h)
+        ctx.set_mode(1)
+        return img
+
+    ctx.set_mode(1)
+    for w, h in ((1024, 520), (1100, 500), (1024, 520)):      # 8320, 8694 tiles; the first size again
+        for cam in cams:
+            ctx.set_camera(*cam)
+            got = ctx.render(w, h)
+            assert np.array_equal(got, reference(w, h, cam)), (w, h, cam)
+    # one part of a split: its own tiles, its own lists (2048 x 1040: 16640 tiles a part)
+    w, h = 2048, 1040
+    for cam in cams[:3]:
+        ctx.set_camera(*cam)
+        full = reference(w, h, cam)
+        for part in (1, 0, 1):
+            ctx.set_camera(*cam)
+            bands = ctx.render_bands(w, h, part, 2)
+            assert np.array_equal(bands, full[vr.band_row_indices(h, part, 2)]), (cam, part)
+
+
 # ---- histogram (prepareHistogramVolumeData, main.cpp:166-181) -----------------------------------
 
 def test_tune_keeps_the_frame(ctx, oracle):

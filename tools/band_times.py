@@ -23,7 +23,9 @@ ctx.set_sampling(bench.samples_for(n))
 ctx.set_mode(1)
 out = torch.empty(w * h * 4, dtype=torch.uint8, device="cuda")
 torch.cuda.synchronize()
-frames = 36
+# the orbit of the benchmark: 1 degree a frame (BAND_STEP), all the way round
+step = int(os.environ.get("BAND_STEP", "1"))
+frames = 360 // step
 out2 = torch.empty(w * h * 4, dtype=torch.uint8, device="cuda")
 PARTS = [int(x) for x in os.environ.get("BAND_PARTS", "1,2,4,8").split(",")]
 for depth in [int(x) for x in os.environ.get("BAND_DEPTHS", "1,2").split(",")]:
@@ -38,7 +40,7 @@ for depth in [int(x) for x in os.environ.get("BAND_DEPTHS", "1,2").split(",")]:
         ctx.synchronize()
         t0 = time.perf_counter()
         for i in range(frames):
-            ctx.set_camera(*bench.orbit_camera(i * 10))
+            ctx.set_camera(*bench.orbit_camera(i * step))
             ctx.render_bands(w, h, part, parts, ptr=(out, out2)[i & 1].data_ptr())
         ctx.synchronize()
         worst = max(worst, (time.perf_counter() - t0) / frames * 1e3)

@@ -381,10 +381,9 @@ __device__ __forceinline__ void stage_lut(float4 *s_lut, const float4 *lut, cons
 // through the grid whatever the block size.
 // Returns false for lanes outside the rectangle.  out_index is the pixel's position in the output
 // buffer: rectangle rows, or with a sort-first split the rows of this part's bands, contiguous.
-__device__ __forceinline__ bool lane_pixel(const FrameParams &fp, int &px, int &py, uint32_t &out_index)
+__device__ __forceinline__ bool lane_pixel_of_tile(const FrameParams &fp, int tile, int &px, int &py, uint32_t &out_index)
 {
     const int lane = threadIdx.x & 63;
-    const int tile = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     const int rect_w = fp.x1 - fp.x0;
     const int tiles_x = (rect_w + 7) >> 3;
     const int tx = tile % tiles_x, trow = tile / tiles_x;     // trow: 8-row tile row local to this part
@@ -393,6 +392,10 @@ __device__ __forceinline__ bool lane_pixel(const FrameParams &fp, int &px, int &
     py = fp.y0 + ((local_row >> 4) * fp.parts + fp.part) * 16 + (local_row & 15);
     out_index = (uint32_t)(local_row * rect_w + (px - fp.x0));
     return px < fp.x1 && py < fp.y1;
+}
+__device__ __forceinline__ bool lane_pixel(const FrameParams &fp, int &px, int &py, uint32_t &out_index)
+{
+    return lane_pixel_of_tile(fp, (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)), px, py, out_index);
 }
 
 // Inverse of out_index -> pixel, for the replay queue.

@@ -1450,21 +1450,85 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
 #endif
 }
 
+// Longest tiles first.  The waves of a launch take very different times (a tile of background 6 us, a tile
+// on the silhouette up to 250), and the launch ends when the last of them does: in launch order the last
+// heavy tiles of the image run on a nearly empty chip.  Every wave therefore notes how long its tile took;
+// k_order_tiles sorts the tiles into kOrderBuckets lists by that time, and the next launch over the same
+// tiles hands them out list after list, longest first, so what is left for the end are the short ones.  The camera moves little from frame
+// to frame, and any permutation of the tiles gives the same frame, so a stale order only costs time.
+// Layout of an order buffer (uint32): [0, kOrderBuckets) entries per list, lists from kOrderLists on,
+// `cap` entries apart.
+constexpr int kOrderBuckets = 16;
+constexpr int kOrderLists = 32;
+constexpr int kOrderShift = 11;   // list = 15 - duration / 2^11 ticks of 10 ns: 20 us a list
+
+// The tile wave `wave_id` of `tiles` renders: its own in launch order, or entry wave_id of the lists.
+__device__ __forceinline__ uint32_t ordered_tile(const uint32_t *__restrict__ order_in, uint32_t cap, uint32_t wave_id, uint32_t tiles)
+{
+    if (!order_in || wave_id >= tiles) return wave_id;
+    const uint32_t mine = order_in[threadIdx.x & (kOrderBuckets - 1)];
+    uint32_t before = 0, tile = wave_id;
+    bool found = false;
+#pragma unroll
+    for (int b = 0; b < kOrderBuckets; b++) {
+        const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)mine, b);
+        if (!found && wave_id - before < n) {
+            tile = order_in[kOrderLists + (size_t)b * cap + (wave_id - before)];
+            found = true;
+        }
+        before += n;
+    }
+    // lists that do not hold exactly this launch's tiles are not used by any wave
+    return before == tiles && tile < tiles ? tile : wave_id;
+}
+
+// The lists for the next launch out of the times the waves of this one noted (ticks of 10 ns per tile; a
+// plain store per wave: 130 000 atomic additions on sixteen words at the end of the waves cost a third of
+// the march).  One thread per tile; a block ranks its tiles per list in LDS and reserves room in each
+// list with one addition, so the tiles of a list stay in image order block after block.
+__global__ __launch_bounds__(1024) void k_order_tiles(const uint32_t *__restrict__ ticks, uint32_t tiles, uint32_t *__restrict__ order,
+                                                      uint32_t cap)
+{
+    __shared__ uint32_t s_count[kOrderBuckets], s_base[kOrderBuckets];
+    if (threadIdx.x < kOrderBuckets) s_count[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t b = 0, rank = 0;
+    if (i < tiles) {
+        const uint32_t t = ticks[i] >> kOrderShift;
+        b = t >= (uint32_t)kOrderBuckets ? 0u : (uint32_t)(kOrderBuckets - 1) - t;
+        rank = atomicAdd(&s_count[b], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < kOrderBuckets) s_base[threadIdx.x] = atomicAdd(&order[threadIdx.x], s_count[threadIdx.x]);
+    __syncthreads();
+    if (i < tiles) order[kOrderLists + (size_t)b * cap + s_base[b] + rank] = i;
+}
+
 template <typename T, bool STATS, bool SHADE>
 __global__ __launch_bounds__(256, (STATS || SHADE) ? 1 : VR_FAST_MIN_WAVES) void k_march_fast(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
                                                    float4 border, const LutInfo *__restrict__ info,
                                                    uint32_t *__restrict__ out, Counters *ctr, uint32_t *touched,
                                                    ReplayRay *__restrict__ queue, LongRay *__restrict__ long_queue, int budget,
-                                                   const uint2 *__restrict__ tiles, int tiles_x)
+                                                   const uint2 *__restrict__ tiles, int tiles_x,
+                                                   const uint32_t *__restrict__ order_in, uint32_t *__restrict__ ticks_out,
+                                                   uint32_t order_cap, uint32_t order_tiles)
 {
     __shared__ float4 s_lut[kLutLds];
+    const unsigned long long began = ticks_out ? wall_clock64() : 0ull;
     stage_lut(s_lut, lut, border);
     const Decider dec(info);
     int px, py;
     uint32_t pixel_id;
-    const bool in_rect = lane_pixel(fp, px, py, pixel_id);
+    const uint32_t wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t tile = ordered_tile(order_in, order_cap, wave_id, order_tiles);
+    const bool in_rect = lane_pixel_of_tile(fp, (int)tile, px, py, pixel_id);
     march_lanes<T, STATS, false, SHADE>(vol, fp, s_lut, dec, out, ctr, touched, queue, long_queue, &ctr->long_count, budget, in_rect, px,
                                  py, pixel_id, nullptr, tiles, tiles_x);
+    if (ticks_out && wave_id < order_tiles && (threadIdx.x & 63) == 0) {
+        const unsigned long long ticks = wall_clock64() - began;
+        ticks_out[tile] = ticks > 0xffffffffull ? 0xffffffffu : (uint32_t)ticks;
+    }
 }
 
 // What a run of consecutive taps does to the light behind it, taken front to back from full
