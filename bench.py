@@ -254,20 +254,21 @@ def run_sort_first(args, su):
     sf = SortFirstFrame(w, h, rank, world, device, host_staging=su.backend != "nccl")
     lib_stream = torch.cuda.ExternalStream(ctx.stream, device=device)
     target = sf.frame if world == 1 else sf.local
-    # Two frames in flight: the few rays a frame's main march hands over are finished beside the next
-    # frame's march, so consecutive frames go to two output buffers in turn.  Every frame is complete
-    # when the timed region ends (fence() waits for both streams).
+    # Frames in flight: the few rays a frame's main march hands over are finished beside the marches of the
+    # next two frames, so consecutive frames go to three output buffers in turn (a frame that reuses the
+    # buffer of one still being finished would wait for it).  Every frame is complete when the timed region
+    # ends (fence() waits for all streams).
     ctx.set_pipeline(2)
-    targets = [target, torch.zeros_like(target)] if world == 1 else None
+    targets = [target, torch.zeros_like(target), torch.zeros_like(target)] if world == 1 else None
     torch.cuda.synchronize()     # the fill ran on torch's stream, the frames are written on the context's
-    gathered = [None, None]      # per band buffer: event after the gather that last read it
+    gathered = [None] * len(sf.locals)   # per band buffer: event after the gather that last read it
 
     def frame(step):
         ctx.set_camera(*su.camera(step))
         if world == 1:
-            ctx.render_bands(w, h, 0, 1, ptr=targets[step & 1].data_ptr())
+            ctx.render_bands(w, h, 0, 1, ptr=targets[step % 3].data_ptr())
             return
-        # two band buffers in turn: this frame is rendered while the previous one is still in the gather
+        # band buffers in turn: this frame is rendered while the previous ones are still finished and gathered
         turn = sf.turn
         if gathered[turn] is not None:
             lib_stream.wait_event(gathered[turn])

@@ -26,7 +26,7 @@ torch.cuda.synchronize()
 # the orbit of the benchmark: 1 degree a frame (BAND_STEP), all the way round
 step = int(os.environ.get("BAND_STEP", "1"))
 frames = 360 // step
-out2 = torch.empty(w * h * 4, dtype=torch.uint8, device="cuda")
+outs = [out] + [torch.empty(w * h * 4, dtype=torch.uint8, device="cuda") for _ in range(2)]
 PARTS = [int(x) for x in os.environ.get("BAND_PARTS", "1,2,4,8").split(",")]
 for depth in [int(x) for x in os.environ.get("BAND_DEPTHS", "1,2").split(",")]:
   ctx.set_pipeline(depth)
@@ -36,12 +36,12 @@ for depth in [int(x) for x in os.environ.get("BAND_DEPTHS", "1,2").split(",")]:
     for part in range(parts):
         for i in range(2):
             ctx.set_camera(*bench.orbit_camera(i))
-            ctx.render_bands(w, h, part, parts, ptr=(out, out2)[i & 1].data_ptr())
+            ctx.render_bands(w, h, part, parts, ptr=outs[i % 3].data_ptr())
         ctx.synchronize()
         t0 = time.perf_counter()
         for i in range(frames):
             ctx.set_camera(*bench.orbit_camera(i * step))
-            ctx.render_bands(w, h, part, parts, ptr=(out, out2)[i & 1].data_ptr())
+            ctx.render_bands(w, h, part, parts, ptr=outs[i % 3].data_ptr())
         ctx.synchronize()
         worst = max(worst, (time.perf_counter() - t0) / frames * 1e3)
     print("parts %d: slowest part %.3f ms per frame" % (parts, worst), flush=True)

@@ -104,33 +104,47 @@ struct vr_ctx {
     int long_group = 0;       // lanes per handed-over ray in k_march_long: 0 = by frame size, else 32 or 64 (VR_LONG_GROUP)
     int tail_blocks = 8192;   // grid of the wave-per-ray kernels: more, shorter queues per wave even out the rays' lengths (VR_TAIL_BLOCKS)
     hipStream_t tail_stream = nullptr;
-    hipEvent_t main_done[2] = {nullptr, nullptr}, tail_done[2] = {nullptr, nullptr}, frame_done = nullptr;
-    bool tail_busy[2] = {false, false};
+    // Three sets of per-frame buffers in turn (set 0: the buffers above).  The kernels that finish frame n
+    // get their execution slots as the march of frame n + 1 drains, so they end about when that march does;
+    // with two sets the march of frame n + 2 had to wait for them (a tenth of the frame time), with three it
+    // follows the march of frame n + 1 directly.
+    static constexpr int kSets = 3;
+    hipEvent_t main_done[kSets] = {nullptr, nullptr, nullptr}, tail_done[kSets] = {nullptr, nullptr, nullptr}, frame_done = nullptr;
+    bool tail_busy[kSets] = {false, false, false};
+    // a set's counters are cleared behind the frame's last kernel, on that kernel's stream, so that the
+    // next frame on the set need not do it in front of its march (two small kernels between two marches)
+    bool counters_clean[kSets] = {false, false, false};
+    // output of the frame a set last rendered: a frame that writes into memory one of the frames still being
+    // finished writes into waits for that frame first
+    const unsigned char *set_out[kSets] = {nullptr, nullptr, nullptr};
+    size_t set_out_bytes[kSets] = {0, 0, 0};
     int last_set = -1;
     uint64_t pipe_index = 0;
-    vr::Counters *counters_alt = nullptr;
-    vr::ReplayRay *queue_alt = nullptr;
-    vr::LongRay *long_alt = nullptr;
+    vr::Counters *counters_alt[kSets - 1] = {nullptr, nullptr};
+    vr::ReplayRay *queue_alt[kSets - 1] = {nullptr, nullptr};
+    vr::LongRay *long_alt[kSets - 1] = {nullptr, nullptr};
     size_t alt_queue_cap = 0;
     // Two frames in flight: the per-tile depth ranges of a frame depend on the camera alone, so they are
     // built on a third stream while the previous frame is still marching; three range buffers in turn, as a
     // buffer is read until its frame's replay has finished (two frames later at most).
     hipStream_t prep_stream = nullptr;
-    uint2 *tiles_ring[3] = {nullptr, nullptr, nullptr};
+    static constexpr int kRangeRing = 4;   // one more than the frames whose kernels can be running
+    uint2 *tiles_ring[kRangeRing] = {nullptr, nullptr, nullptr, nullptr};
     size_t tiles_ring_cap = 0;
-    hipEvent_t ranges_done[3] = {nullptr, nullptr, nullptr}, ranges_free[3] = {nullptr, nullptr, nullptr};
-    bool ranges_busy[3] = {false, false, false};
+    hipEvent_t ranges_done[kRangeRing] = {nullptr, nullptr, nullptr, nullptr}, ranges_free[kRangeRing] = {nullptr, nullptr, nullptr, nullptr};
+    bool ranges_busy[kRangeRing] = {false, false, false, false};
     uint64_t ring_index = 0;
     // Longest tiles first (vr::ordered_tile), for frames rendered one at a time: the lane march of a fast
     // frame notes how long each tile took, k_order_tiles sorts the tiles by that time behind the frame's last
     // kernel, and the next frame that uses the same set of per-frame buffers launches its tiles in that order
     // when it covers the same tiles.
     bool tile_order = true;             // VR_TILE_ORDER=0 switches it off
-    uint32_t *order_lists[2] = {nullptr, nullptr};   // per set of per-frame buffers
-    uint32_t *tile_ticks[2] = {nullptr, nullptr};    // time every tile took, per set
+    bool tile_order_piped = false;      // VR_TILE_ORDER=2: also with two frames in flight (for measurements)
+    uint32_t *order_lists[kSets] = {nullptr, nullptr, nullptr};   // per set of per-frame buffers
+    uint32_t *tile_ticks[kSets] = {nullptr, nullptr, nullptr};    // time every tile took, per set
     size_t order_cap = 0;               // tiles per list
-    bool order_valid[2] = {false, false};
-    int order_key[2][7] = {{0}, {0}};   // the rectangle, split and tile count the lists of a set are for
+    bool order_valid[kSets] = {false, false, false};
+    int order_key[kSets][7] = {{0}, {0}, {0}};   // the rectangle, split and tile count the lists of a set are for
     // test hook (VR_TEST_FAIL_ALLOC=n at vr_create): the n-th device allocation of a volume upload
     // fails, so that the error path of the upload can be exercised without exhausting the GPU
     int fail_alloc_in = 0;
@@ -194,7 +208,7 @@ int bind(vr_ctx *ctx)
 // whatever is enqueued next may overwrite what they read.
 void drain(vr_ctx *ctx)
 {
-    for (int k = 0; k < 2; k++)
+    for (int k = 0; k < vr_ctx::kSets; k++)
         if (ctx->tail_busy[k]) {
             (void)hipStreamWaitEvent(ctx->stream, ctx->tail_done[k], 0);
             ctx->tail_busy[k] = false;
@@ -441,6 +455,7 @@ struct FrameBuffers {
     hipEvent_t ranges_done;  // recorded on `prep` after the ranges are built
     hipEvent_t ranges_free;  // to wait for on `prep` before the range buffer is overwritten, or null
     bool may_order;          // the frame may use (and allocate) the context's tile-order lists
+    bool clear_after;        // clear the counters behind the frame's last kernel
     int set;                 // which of the two sets of per-frame buffers this is
 };
 
@@ -505,7 +520,7 @@ void launch_frame_as(vr_ctx *ctx, const vr::FrameParams &fp, uint32_t *d_out, co
         uint32_t *order_out = nullptr, *ticks = nullptr;
         if (!STATS && fb.may_order && ctx->tile_order && tile_waves >= 8192) {
             if ((size_t)tile_waves > ctx->order_cap) {
-                for (int k = 0; k < 2; k++) {
+                for (int k = 0; k < vr_ctx::kSets; k++) {
                     if (ctx->order_lists[k]) (void)hipFree(ctx->order_lists[k]);
                     if (ctx->tile_ticks[k]) (void)hipFree(ctx->tile_ticks[k]);
                     ctx->order_lists[k] = ctx->tile_ticks[k] = nullptr;
@@ -514,7 +529,7 @@ void launch_frame_as(vr_ctx *ctx, const vr::FrameParams &fp, uint32_t *d_out, co
                 ctx->order_cap = 0;
                 const size_t words = (size_t)vr::kOrderLists + (size_t)vr::kOrderBuckets * (size_t)tile_waves;
                 bool ok = true;
-                for (int k = 0; k < 2 && ok; k++)
+                for (int k = 0; k < vr_ctx::kSets && ok; k++)
                     ok = hipMalloc(&ctx->order_lists[k], words * sizeof(uint32_t)) == hipSuccess &&
                          hipMalloc(&ctx->tile_ticks[k], (size_t)tile_waves * sizeof(uint32_t)) == hipSuccess;
                 if (ok) ctx->order_cap = (size_t)tile_waves;
@@ -547,6 +562,7 @@ void launch_frame_as(vr_ctx *ctx, const vr::FrameParams &fp, uint32_t *d_out, co
         else
             hipLaunchKernelGGL((vr::k_march_long<T, 64, STATS, SHADE>), replay_grid, dim3(256), 0, ts, vol, fp, lut, border, ctx->lut_info, d_out, fb.counters, ctx->touched, fb.queue, fb.long_queue);
         hipLaunchKernelGGL((vr::k_replay_exact<T, STATS, SHADE>), replay_grid, dim3(256), 0, ts, vol, fp, lut, border, ctx->lut_info, d_out, fb.counters, ctx->touched, fb.queue, tiles, tiles_x);
+        if (fb.clear_after) (void)hipMemsetAsync(fb.counters, 0, offsetof(vr::Counters, lut_error), ts);
         if (order_out) {
             // behind the frame's last kernel: the march before it has read these lists, and the next reader is
             // the march of the next frame on this set of buffers, which waits for this set's last kernels
@@ -596,7 +612,10 @@ int vr_create(int device, vr_ctx **out)
     }
     if (const char *e = std::getenv("VR_TEST_FAIL_ALLOC")) ctx->fail_alloc_in = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("VR_TILE_CLIP")) ctx->tile_clip = std::atoi(e) != 0;
-    if (const char *e = std::getenv("VR_TILE_ORDER")) ctx->tile_order = std::atoi(e) != 0;
+    if (const char *e = std::getenv("VR_TILE_ORDER")) {
+        ctx->tile_order = std::atoi(e) != 0;
+        ctx->tile_order_piped = std::atoi(e) == 2;
+    }
     if (const char *e = std::getenv("VR_LANE_BUDGET")) ctx->lane_budget = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("VR_PARTIAL_BUDGET")) ctx->partial_budget = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("VR_LONG_GROUP")) ctx->long_group = std::atoi(e) == 32 ? 32 : (std::atoi(e) == 64 ? 64 : 0);
@@ -629,18 +648,20 @@ int vr_destroy(vr_ctx *ctx)
     if (ctx->prep_stream) (void)hipStreamSynchronize(ctx->prep_stream);
     if (ctx->tail_stream) (void)hipStreamSynchronize(ctx->tail_stream);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    ctx->tail_busy[0] = ctx->tail_busy[1] = false;
+    for (int k = 0; k < vr_ctx::kSets; k++) ctx->tail_busy[k] = false;
     release_volume(ctx);
-    if (ctx->counters_alt) (void)hipFree(ctx->counters_alt);
-    if (ctx->queue_alt) (void)hipFree(ctx->queue_alt);
-    if (ctx->long_alt) (void)hipFree(ctx->long_alt);
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < vr_ctx::kSets - 1; k++) {
+        if (ctx->counters_alt[k]) (void)hipFree(ctx->counters_alt[k]);
+        if (ctx->queue_alt[k]) (void)hipFree(ctx->queue_alt[k]);
+        if (ctx->long_alt[k]) (void)hipFree(ctx->long_alt[k]);
+    }
+    for (int k = 0; k < vr_ctx::kRangeRing; k++) {
         if (ctx->tiles_ring[k]) (void)hipFree(ctx->tiles_ring[k]);
         if (ctx->ranges_done[k]) (void)hipEventDestroy(ctx->ranges_done[k]);
         if (ctx->ranges_free[k]) (void)hipEventDestroy(ctx->ranges_free[k]);
     }
     if (ctx->prep_stream) (void)hipStreamDestroy(ctx->prep_stream);
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < vr_ctx::kSets; k++) {
         if (ctx->main_done[k]) (void)hipEventDestroy(ctx->main_done[k]);
         if (ctx->tail_done[k]) (void)hipEventDestroy(ctx->tail_done[k]);
     }
@@ -657,7 +678,7 @@ int vr_destroy(vr_ctx *ctx)
     if (ctx->occ) (void)hipFree(ctx->occ);
     if (ctx->d_occ_count) (void)hipFree(ctx->d_occ_count);
     if (ctx->tiles) (void)hipFree(ctx->tiles);
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < vr_ctx::kSets; k++) {
         if (ctx->order_lists[k]) (void)hipFree(ctx->order_lists[k]);
         if (ctx->tile_ticks[k]) (void)hipFree(ctx->tile_ticks[k]);
     }
@@ -693,17 +714,19 @@ int vr_set_pipeline(vr_ctx *ctx, int frames_in_flight)
     drain(ctx);
     if (frames_in_flight == 2 && !ctx->tail_stream) {
         // the second stream, its events and the second set of counters exist only in contexts that ask for them
-        for (int k = 0; k < 2; k++) {
+        for (int k = 0; k < vr_ctx::kSets; k++) {
             VR_HIP(ctx, hipEventCreateWithFlags(&ctx->main_done[k], hipEventDisableTiming));
             VR_HIP(ctx, hipEventCreateWithFlags(&ctx->tail_done[k], hipEventDisableTiming));
         }
-        for (int k = 0; k < 3; k++) {
+        for (int k = 0; k < vr_ctx::kRangeRing; k++) {
             VR_HIP(ctx, hipEventCreateWithFlags(&ctx->ranges_done[k], hipEventDisableTiming));
             VR_HIP(ctx, hipEventCreateWithFlags(&ctx->ranges_free[k], hipEventDisableTiming));
         }
         VR_HIP(ctx, hipStreamCreateWithFlags(&ctx->prep_stream, hipStreamNonBlocking));
-        VR_HIP(ctx, hipMalloc(&ctx->counters_alt, sizeof(vr::Counters)));
-        VR_HIP(ctx, hipMemsetAsync(ctx->counters_alt, 0, sizeof(vr::Counters), ctx->stream));
+        for (int k = 0; k < vr_ctx::kSets - 1; k++) {
+            VR_HIP(ctx, hipMalloc(&ctx->counters_alt[k], sizeof(vr::Counters)));
+            VR_HIP(ctx, hipMemsetAsync(ctx->counters_alt[k], 0, sizeof(vr::Counters), ctx->stream));
+        }
         // The finishing kernels are short chains of dependent steps and may be given their few waves first
         // (VR_TAIL_PRIORITY=1).  Opt-in: with several processes sharing one GPU a high-priority queue was
         // seen to stall the other processes' queues for good, so it is only meant for a GPU of one's own.
@@ -1121,53 +1144,72 @@ static int render_impl(vr_ctx *ctx, int width, int height, int x0, int y0, int x
                           reinterpret_cast<vr::LongRay *>(sp + static_scratch::kLongAt),
                           reinterpret_cast<uint2 *>(sp + static_scratch::kTilesAt), ctx->stream, nullptr, nullptr, nullptr, nullptr};
     int set = 0, ring = -1;
+    hipStream_t main_s = ctx->stream;
     if (piped) {
-        set = (int)(ctx->pipe_index++ & 1u);
+        set = (int)(ctx->pipe_index++ % (uint64_t)vr_ctx::kSets);
         const int tile_px = 1 << vr::kRangeShift;
         const size_t tile_count = (size_t)((width + tile_px - 1) / tile_px) * (size_t)((height + tile_px - 1) / tile_px);
         if (pixels > ctx->alt_queue_cap || tile_count > ctx->tiles_ring_cap) {
             drain(ctx);
             VR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            if (ctx->queue_alt) (void)hipFree(ctx->queue_alt);
-            if (ctx->long_alt) (void)hipFree(ctx->long_alt);
-            ctx->queue_alt = nullptr; ctx->long_alt = nullptr;
+            for (int k = 0; k < vr_ctx::kSets - 1; k++) {
+                if (ctx->queue_alt[k]) (void)hipFree(ctx->queue_alt[k]);
+                if (ctx->long_alt[k]) (void)hipFree(ctx->long_alt[k]);
+                ctx->queue_alt[k] = nullptr;
+                ctx->long_alt[k] = nullptr;
+            }
             ctx->alt_queue_cap = 0;
-            for (int k = 0; k < 3; k++) {
+            for (int k = 0; k < vr_ctx::kRangeRing; k++) {
                 if (ctx->tiles_ring[k]) (void)hipFree(ctx->tiles_ring[k]);
                 ctx->tiles_ring[k] = nullptr;
                 ctx->ranges_busy[k] = false;
             }
             ctx->tiles_ring_cap = 0;
-            VR_HIP(ctx, hipMalloc(&ctx->queue_alt, pixels * sizeof(vr::ReplayRay)));
-            VR_HIP(ctx, hipMalloc(&ctx->long_alt, pixels * sizeof(vr::LongRay)));
-            for (int k = 0; k < 3; k++) VR_HIP(ctx, hipMalloc(&ctx->tiles_ring[k], (tile_count + 1) * sizeof(uint2)));
+            for (int k = 0; k < vr_ctx::kSets - 1; k++) {
+                VR_HIP(ctx, hipMalloc(&ctx->queue_alt[k], pixels * sizeof(vr::ReplayRay)));
+                VR_HIP(ctx, hipMalloc(&ctx->long_alt[k], pixels * sizeof(vr::LongRay)));
+            }
+            for (int k = 0; k < vr_ctx::kRangeRing; k++) VR_HIP(ctx, hipMalloc(&ctx->tiles_ring[k], (tile_count + 1) * sizeof(uint2)));
             ctx->alt_queue_cap = pixels;
             ctx->tiles_ring_cap = tile_count;
         }
-        if (set == 1) fb = FrameBuffers{ctx->counters_alt, ctx->queue_alt, ctx->long_alt, nullptr, ctx->stream, nullptr, nullptr, nullptr, nullptr};
-        ring = (int)(ctx->ring_index++ % 3u);
+        if (set > 0)
+            fb = FrameBuffers{ctx->counters_alt[set - 1], ctx->queue_alt[set - 1], ctx->long_alt[set - 1], nullptr, ctx->stream, nullptr, nullptr, nullptr, nullptr};
+        ring = (int)(ctx->ring_index++ % (uint64_t)vr_ctx::kRangeRing);
         fb.tiles = ctx->tiles_ring[ring];
         fb.prep = ctx->prep_stream;
         fb.ranges_done = ctx->ranges_done[ring];
         fb.ranges_free = ctx->ranges_busy[ring] ? ctx->ranges_free[ring] : nullptr;
-        // this set's buffers were last used by the frame before the previous one
-        if (ctx->tail_busy[set]) {
-            VR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->tail_done[set], 0));
-            ctx->tail_busy[set] = false;
+        // this set's buffers were last used two frames ago; and whatever frame still being finished writes
+        // into the memory this frame is going to write into comes first
+        const unsigned char *o0 = reinterpret_cast<const unsigned char *>(d_out), *o1 = o0 + pixels * 4;
+        for (int k = 0; k < vr_ctx::kSets; k++) {
+            if (!ctx->tail_busy[k]) continue;
+            const bool overlaps = ctx->set_out[k] < o1 && o0 < ctx->set_out[k] + ctx->set_out_bytes[k];
+            if (k == set || overlaps) {
+                VR_HIP(ctx, hipStreamWaitEvent(main_s, ctx->tail_done[k], 0));
+                ctx->tail_busy[k] = false;
+            }
         }
+        ctx->set_out[set] = o0;
+        ctx->set_out_bytes[set] = pixels * 4;
         fb.tail = ctx->tail_stream;
         fb.main_done = ctx->main_done[set];
     }
     // with two frames in flight the kernels that finish a frame fill the end of the next frame's march
     // already; the longest tiles first then only competes with them (measured: 1 to 3 % slower)
-    fb.may_order = !use_static && !piped;
+    fb.may_order = !use_static && (!piped || ctx->tile_order_piped);
     fb.set = set;
     // the counters also carry the fast march's queue fill, so they are cleared every frame
-    VR_HIP(ctx, hipMemsetAsync(fb.counters, 0, offsetof(vr::Counters, lut_error), ctx->stream));
+    if (!(piped && ctx->counters_clean[set])) VR_HIP(ctx, hipMemsetAsync(fb.counters, 0, offsetof(vr::Counters, lut_error), main_s));
+    for (int k = 0; k < vr_ctx::kSets; k++)
+        if (k == set || !piped) ctx->counters_clean[k] = false;   // frames outside the pipeline use set 0's and tell nobody
+    fb.clear_after = piped && !ctx->fast_probe;    // the probe frame's counters are read after the frame
+    if (fb.clear_after) ctx->counters_clean[set] = true;
     if (want_stats)
-        VR_HIP(ctx, hipMemsetAsync(ctx->touched, 0, ((ctx->brick_count + 31) / 32) * sizeof(uint32_t), ctx->stream));
+        VR_HIP(ctx, hipMemsetAsync(ctx->touched, 0, ((ctx->brick_count + 31) / 32) * sizeof(uint32_t), main_s));
 
-    VR_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    if (!piped) VR_HIP(ctx, hipEventRecord(ctx->ev0, main_s));
     if (ctx->dtype == VR_DTYPE_U8)
         launch_frame<uint8_t>(ctx, fp, d_out, want_stats, fb);
     else
@@ -1182,14 +1224,14 @@ static int render_impl(vr_ctx *ctx, int width, int height, int x0, int y0, int x
     } else {
         ctx->last_set = -1;
     }
-    VR_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    if (!piped) VR_HIP(ctx, hipEventRecord(ctx->ev1, main_s));
 
     if (fast && ctx->fast_probe && pixels >= 4096) {
         // the probe frame: how many of its pixels went through the replay?
         vr::Counters c;
         if (piped) VR_HIP(ctx, hipStreamSynchronize(ctx->tail_stream));
-        VR_HIP(ctx, hipMemcpyAsync(&c, fb.counters, sizeof c, hipMemcpyDeviceToHost, ctx->stream));
-        VR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        VR_HIP(ctx, hipMemcpyAsync(&c, fb.counters, sizeof c, hipMemcpyDeviceToHost, main_s));
+        VR_HIP(ctx, hipStreamSynchronize(main_s));
         ctx->fast_probe = false;
         ctx->fast_fallback = (size_t)c.replay_count * 10u > pixels;
     }
@@ -1291,12 +1333,10 @@ int vr_tune(vr_ctx *ctx, int width, int height, int part, int parts, int *chosen
     }
     if (int rc = bind(ctx)) return rc;
     const size_t pixels = (size_t)width * (size_t)rows_of_part(height, part, parts);
-    uint8_t *scratch[2] = {nullptr, nullptr};
-    VR_HIP(ctx, hipMalloc(&scratch[0], pixels * 4));
-    if (hipMalloc(&scratch[1], pixels * 4) != hipSuccess) {
-        (void)hipFree(scratch[0]);
-        return fail(ctx, VR_ERR_HIP, "hipMalloc failed");
-    }
+    // one allocation, three frames in turn (frames in flight must not share their output)
+    const size_t frame_bytes = (pixels * 4 + 255) & ~(size_t)255;
+    uint8_t *scratch = nullptr;
+    VR_HIP(ctx, hipMalloc(&scratch, 3 * frame_bytes));
     const int mode = ctx->mode, before = ctx->lane_budget;
     ctx->mode = VR_MODE_FAST;
     // How long a lane stays with its ray before it hands it to a wave of its own: the best value
@@ -1313,7 +1353,7 @@ int vr_tune(vr_ctx *ctx, int width, int height, int part, int parts, int *chosen
         for (int rep = 0; rep < 3 && rc == VR_OK; rep++) {      // the first run also warms the caches (and is the fast mode's probe)
             const auto t0 = std::chrono::steady_clock::now();
             for (int k = 0; k < kRun && rc == VR_OK; k++)
-                rc = render_impl(ctx, width, height, 0, 0, width, height, part, parts, scratch[k & 1], 1, nullptr);
+                rc = render_impl(ctx, width, height, 0, 0, width, height, part, parts, scratch + (size_t)(k % 3) * frame_bytes, 1, nullptr);
             if (rc == VR_OK) rc = vr_synchronize(ctx);
             const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             if (rep > 0 && s < fastest) fastest = s;
@@ -1328,8 +1368,7 @@ int vr_tune(vr_ctx *ctx, int width, int height, int part, int parts, int *chosen
     ctx->mode = mode;
     drain(ctx);
     (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(scratch[0]);
-    (void)hipFree(scratch[1]);
+    (void)hipFree(scratch);
     if (rc == VR_OK && chosen_budget) *chosen_budget = best;
     return rc;
 }
@@ -1386,6 +1425,7 @@ int vr_count_hit_rays(vr_ctx *ctx, int width, int height, int x0, int y0, int x1
     std::memcpy(fp.scene, ctx->scene, sizeof fp.scene);
     drain(ctx);
     VR_HIP(ctx, hipMemsetAsync(ctx->counters, 0, offsetof(vr::Counters, lut_error), ctx->stream));
+    ctx->counters_clean[0] = false;
     const int tiles = ((x1 - x0 + 7) / 8) * 2 * ((y1 - y0 + 15) / 16);
     hipLaunchKernelGGL(vr::k_count_hits, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, ctx->stream, fp, &ctx->counters->rays_hit);
     unsigned long long h = 0;
@@ -1516,6 +1556,7 @@ int vr_render_partial(vr_ctx *ctx, int width, int height, float *out, int out_is
     }
     if (int rc = refresh_occupancy(ctx)) return rc;
     VR_HIP(ctx, hipMemsetAsync(ctx->counters, 0, offsetof(vr::Counters, lut_error), ctx->stream));
+    ctx->counters_clean[0] = false;
     const int tiles = ((width + 7) / 8) * 2 * ((height + 15) / 16);
     const vr::VolumeView vol = view_of(ctx);
     const float4 border = make_float4(ctx->border[0], ctx->border[1], ctx->border[2], ctx->border[3]);

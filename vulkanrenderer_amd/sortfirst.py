@@ -40,9 +40,10 @@ class SortFirstFrame:
         self.staging = host_staging
         self.rows = band_rows(height, rank, world)
         self.padded_rows = max(band_rows(height, r, world) for r in range(world))
-        # equal-sized buffers on every rank: gather needs them.  Two of them, used in turn, so that a
-        # frame can be rendered while the previous one is still being gathered.
-        self.locals = [torch.zeros((self.padded_rows, width, 4), dtype=torch.uint8, device=self.device) for _ in range(2)]
+        # equal-sized buffers on every rank: gather needs them.  Three of them, used in turn: a frame is
+        # rendered while the one before it is still being finished on the renderer's second stream and the
+        # one before that may still be in the gather.
+        self.locals = [torch.zeros((self.padded_rows, width, 4), dtype=torch.uint8, device=self.device) for _ in range(3)]
         self.turn = 0
         self.recv = None
         self.frame = None
@@ -66,9 +67,9 @@ class SortFirstFrame:
 
     def exchange(self):
         """Gathers every rank's bands on rank 0 and assembles the frame there (returns it on rank 0).
-        Afterwards `local` is the other band buffer."""
+        Afterwards `local` is the next band buffer."""
         local = self.local
-        self.turn ^= 1
+        self.turn = (self.turn + 1) % len(self.locals)
         if self.world == 1:
             # a single part's band buffer already is the frame, row for row
             self.frame.copy_(local[: self.height])
