@@ -196,29 +196,41 @@ __global__ __launch_bounds__(256) void k_decide_partials(FrameParams fp, const L
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= count) return;
     const float *p = partials + (size_t)i * kPartial;
-    const double tr = (double)p[3];
+    const float trf = p[3];
     const float taps = (float)(fp.samples + 2);
-    const float spread = p[4] * 1.001f + ((float)tr + 2.0f * (float)kTrCut) * taps;
+    const float spread = (p[4] * 1.001f + (trf + 2.0f * (float)kTrCut) * taps) * 1.000001f;
     uint32_t bytes = 0xff000000u;
     bool same = info->fast_ok != 0;
+    // the interval ends in float, pushed outwards by more than forming them can lose (5 u of their
+    // magnitude, as in Decider::decide)
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        const double mag = fmax(fabs((double)info->cmin[c]), fabs((double)info->cmax[c]));
-        const double e = (double)info->kappa[c] * (double)spread + (16.0 * (double)kUlpHalf + 2.5 * kTrCut) * mag;
-        double lo = (double)p[c] + tr * (double)info->cmin[c] - e;
-        double hi = (double)p[c] + tr * (double)info->cmax[c] + e;
-        lo -= fabs(lo) * 1e-7 + 1e-38;
-        hi += fabs(hi) * 1e-7 + 1e-38;
-        const uint32_t bl = to_unorm8((float)lo), bh = to_unorm8((float)hi);
+        const float cmin = info->cmin[c], cmax = info->cmax[c];
+        const float mag = fmaxf(fabsf(cmin), fabsf(cmax));
+        const float e = (info->kappa[c] * spread + (16.0f * kUlpHalf + 2.5f * (float)kTrCut) * mag) * 1.000001f;
+        const float m = fabsf(p[c]) + trf * mag + e;
+        const float slack = __builtin_fmaf(m, 5.0f * kUlpHalf, 1e-38f);
+        const float lo = (__builtin_fmaf(trf, cmin, p[c]) - e) - slack;
+        const float hi = (__builtin_fmaf(trf, cmax, p[c]) + e) + slack;
+        const uint32_t bl = to_unorm8(lo), bh = to_unorm8(hi);
         same = same && (bl == bh);
         bytes |= bl << (8 * c);
     }
+    bool listed = false;
     if (!same) {
         // with a table the interval argument does not hold for, every ray that hits is re-marched
         Ray r;
-        const bool hit = ray_of_pixel(fp, first + i, r) && r.hit;
-        if (hit) list[atomicAdd(list_count, 1u)] = first + i;
-        else bytes = 0xff000000u;
+        listed = ray_of_pixel(fp, first + i, r) && r.hit;
+        if (!listed) bytes = 0xff000000u;
+    }
+    // one addition per wave reserves the list entries of its pixels (additions on one word take their turn)
+    const unsigned long long votes = __ballot(listed);
+    if (votes) {
+        const int lane = threadIdx.x & 63;
+        uint32_t base = 0;
+        if (lane == __builtin_ctzll(votes)) base = atomicAdd(list_count, (uint32_t)__popcll(votes));
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(votes));
+        if (listed) list[base + (uint32_t)__popcll(votes & ((1ull << lane) - 1ull))] = first + i;
     }
     out[i] = bytes;
 }
