@@ -9,6 +9,9 @@ out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/bench" -o bench -- python3 "$root/bench.py" --no-cpu-baseline > "$out/bench_under_rocprof.json" 2> "$out/bench.err" || exit 1
+# the benchmark's pipelined frames launch their tiles in image order; profile_frame.py renders one frame at a
+# time, which would launch them longest first: switched off so that the counters describe the benchmark's launches
+export VR_TILE_ORDER=0
 pass() {
   name=$1; shift
   timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d "$out/$name" -o pmc -- python3 "$root/tools/profile_frame.py" --frames 6 > "$out/$name.log" 2>&1 || exit 1
