@@ -580,7 +580,7 @@ __device__ __forceinline__ float axis_span(float g, float lo, float extent, floa
 {
     const float a = lo + margin, b = lo + extent - margin;
     const float target = inv > 0.0f ? b : a;
-    float n = (target - g) * inv * 0.9999f;   // the reciprocal is good to 1 ulp: round the count down
+    float n = (target - g) * inv;
     if (inv == 0.0f) n = 1e9f;                // not moving along this axis
     return (g >= a && g <= b) ? n : -1.0f;
 }
@@ -593,7 +593,7 @@ __device__ __forceinline__ int span_inside(float gx, float gy, float gz, int lox
     float n = axis_span(gx, (float)lox, extent, m.ix, m.margin);
     n = fminf(n, axis_span(gy, (float)loy, extent, m.iy, m.margin));
     n = fminf(n, axis_span(gz, (float)loz, extent, m.iz, m.margin));
-    n = fminf(n, 1e9f);
+    n = fminf(n, 1e9f) * 0.9999f;             // the reciprocals are good to 1 ulp: round the count down
     return n >= 0.0f ? 1 + (int)n : 0;
 }
 
