@@ -69,10 +69,13 @@ print("waves with rounds:", int(busy.sum()), "their dur mean %.1f us, rounds mea
 print("waves without rounds: dur mean %.1f us, both mean %.1f" % (dur[~busy].mean(), mboth[~busy].mean()))
 wave_passes = (t[:, 2] & 0xffff).astype(np.float64)
 first_passes = ((t[:, 2] >> 16) & 0xffff).astype(np.float64)
-lane_passes = (t[:, 2] >> 32).astype(np.float64)
+lane_passes = ((t[:, 2] >> 32) & 0xffff).astype(np.float64)
+pyramid_passes = ((t[:, 2].astype(np.uint64) >> np.uint64(48)) & np.uint64(0xffff)).astype(np.float64)
 print("passes of the skipping loop the WAVE executed: mean %.1f (busy waves %.1f, p90 %.0f); lanes active in a pass: %.1f of 64" % (
     wave_passes.mean(), wave_passes[busy].mean(), np.percentile(wave_passes[busy], 90), lane_passes.sum() / max(1.0, wave_passes.sum())))
 print("of them before the first fetch round (busy waves): %.1f" % first_passes[busy].mean())
+print("passes summed over the lanes of busy waves: %.0f per wave, of them over empty cubes of the pyramid %.0f, over empty 2^3 blocks of occupied bricks or onto a tap %.0f" % (
+    lane_passes[busy].mean(), pyramid_passes[busy].mean(), lane_passes[busy].mean() - pyramid_passes[busy].mean()))
 for lo, hi in ((1, 8), (8, 16), (16, 32), (32, 64), (64, 128), (128, 1e9)):
     sel = busy & (rounds >= lo) & (rounds < hi)
     if sel.any():

@@ -491,10 +491,14 @@ __device__ __forceinline__ void splat_one(const VolumeView &vol, const FramePara
         atomicOr(&tiles[(size_t)tiles_x * tiles_y].x, 1u);
         return;
     }
+    // Distance from the eye (what a tap's index measures along its ray) of the nearest and the farthest point
+    // of the box: per axis the gap to the box, or zero inside its slab, and the farther of the two faces.
     const float cx = 0.5f * (x0 + x1) - fp.loc[0], cy = 0.5f * (y0 + y1) - fp.loc[1], cz = 0.5f * (z0 + z1) - fp.loc[2];
-    const float hx = 0.5f * (x1 - x0), hy = 0.5f * (y1 - y0), hz = 0.5f * (z1 - z0);
-    const float dist = sqrtf(cx * cx + cy * cy + cz * cz), rad = sqrtf(hx * hx + hy * hy + hz * hz) * 1.001f;
-    const float near = fmaxf(dist * 0.99999f - rad, 0.0f), far = dist * 1.00001f + rad;
+    const float hx = 0.5f * fabsf(x1 - x0), hy = 0.5f * fabsf(y1 - y0), hz = 0.5f * fabsf(z1 - z0);
+    const float nx = fmaxf(fabsf(cx) - hx, 0.0f), ny = fmaxf(fabsf(cy) - hy, 0.0f), nz = fmaxf(fabsf(cz) - hz, 0.0f);
+    const float fx = fabsf(cx) + hx, fy = fabsf(cy) + hy, fz = fabsf(cz) + hz;
+    const float near = fmaxf(sqrtf(nx * nx + ny * ny + nz * nz) * 0.9999f - 1e-6f, 0.0f);
+    const float far = sqrtf(fx * fx + fy * fy + fz * fz) * 1.0001f + 1e-6f;
     const int tx0 = max(0, (int)floorf(pxmin - 1.5f) >> kRangeShift), tx1 = min(tiles_x - 1, (int)floorf(pxmax + 1.5f) >> kRangeShift);
     const int ty0 = max(0, (int)floorf(pymin - 1.5f) >> kRangeShift), ty1 = min(tiles_y - 1, (int)floorf(pymax + 1.5f) >> kRangeShift);
     if (tx0 > tx1 || ty0 > ty1) return;   // off screen
@@ -1104,7 +1108,7 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
 {
 #ifdef VR_DIAG
     const unsigned long long diag_t0 = wall_clock64();
-    unsigned int diag_model = 0, diag_exact = 0, diag_rounds = 0, diag_sampled = 0, diag_wave_passes = 0, diag_wave_passes0 = 0;
+    unsigned int diag_model = 0, diag_exact = 0, diag_rounds = 0, diag_sampled = 0, diag_wave_passes = 0, diag_wave_passes0 = 0, diag_pyramid = 0;
     long long diag_c0 = clock64(), diag_setup = 0, diag_skip = 0, diag_sample = 0;
 #endif
     const Ray r = make_ray(fp, in_rect ? px : fp.x0, in_rect ? py : fp.y0);
@@ -1270,6 +1274,9 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
             int lox, loy, loz;
             float extent;
             if (level >= 0) {
+#ifdef VR_DIAG
+                diag_pyramid++;
+#endif
                 const int shift = 3 + 2 * level;
                 lox = (c.sx >> shift) << shift;
                 loy = (c.sy >> shift) << shift;
@@ -1424,6 +1431,7 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
         diag_wave_passes += (unsigned int)__shfl_xor((int)diag_wave_passes, o);
         diag_wave_passes0 += (unsigned int)__shfl_xor((int)diag_wave_passes0, o);
         diag_lane_passes += (unsigned int)__shfl_xor((int)diag_lane_passes, o);
+        diag_pyramid += (unsigned int)__shfl_xor((int)diag_pyramid, o);
         diag_model = max(diag_model, (unsigned int)__shfl_xor((int)diag_model, o));
         diag_exact = max(diag_exact, (unsigned int)__shfl_xor((int)diag_exact, o));
         diag_both = max(diag_both, (unsigned int)__shfl_xor((int)diag_both, o));
@@ -1442,7 +1450,7 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
         g_vr_timeline[wave_id * 8 + 0] = diag_t0;
         g_vr_timeline[wave_id * 8 + 1] = wall_clock64();
         (void)hw; (void)xcc;
-        g_vr_timeline[wave_id * 8 + 2] = (unsigned long long)diag_wave_passes | ((unsigned long long)diag_wave_passes0 << 16) | ((unsigned long long)diag_lane_passes << 32);
+        g_vr_timeline[wave_id * 8 + 2] = (unsigned long long)diag_wave_passes | ((unsigned long long)diag_wave_passes0 << 16) | ((unsigned long long)diag_lane_passes << 32) | ((unsigned long long)diag_pyramid << 48);
         g_vr_timeline[wave_id * 8 + 3] = (unsigned long long)diag_rounds | ((unsigned long long)diag_model << 12) |
                                          ((unsigned long long)diag_exact << 24) | ((unsigned long long)diag_both << 36) |
                                          ((unsigned long long)diag_sum << 48);
