@@ -11,10 +11,10 @@
 
 namespace vr {
 
-// Waves per SIMD the plain fast march is compiled for (register budget 512 / this): 6 measured best
-// (5: -1.6 %, 7: -1.1 %, 8 spills: -37 %); the variants with counters or lighting need more registers.
+// Waves per SIMD the plain fast march is compiled for (register budget 512 / this): 7 measured best
+// (5 and 6: 4 % slower, 8 spills: 19 % slower); the variants with counters or lighting need more registers.
 #ifndef VR_FAST_MIN_WAVES
-#define VR_FAST_MIN_WAVES 6
+#define VR_FAST_MIN_WAVES 7
 #endif
 
 #ifdef VR_DIAG

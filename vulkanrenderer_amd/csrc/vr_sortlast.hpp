@@ -68,8 +68,11 @@ __device__ __forceinline__ float ray_step(const Ray &r, int samples)
 // One lane per ray, front to back over the taps this context owns: the lane march of the whole-volume
 // path (march_lanes) with the ownership test, without the decision.  out: kPartial floats per pixel.
 // A lane that has spent `budget` memory round trips with more to go hands its ray to k_partial_long.
+#ifndef VR_PARTIAL_MIN_WAVES
+#define VR_PARTIAL_MIN_WAVES 7
+#endif
 template <typename T>
-__global__ __launch_bounds__(256) void k_march_partial(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
+__global__ __launch_bounds__(256, VR_PARTIAL_MIN_WAVES) void k_march_partial(VolumeView vol, FrameParams fp, const float4 *__restrict__ lut,
                                                       float4 border, const LutInfo *__restrict__ info,
                                                       float *__restrict__ out, Counters *ctr,
                                                       LongRay *__restrict__ long_queue, int budget,
