@@ -74,7 +74,7 @@ struct vr_ctx {
     float raw_loc[4] = {0, 0, 0, 1};
     float raw_m[16] = {0};
 
-    int waves_per_block = 1;
+    int waves_per_block = 0;   // waves per workgroup of the marches, one tile each; 0: two for launches of 65536 tiles and more (1 % faster there), else one (VR_WAVES_PER_BLOCK)
     // memory round trips (fetch rounds + passes of the skipping loop) a lane spends on a ray before a
     // wave takes the ray over
     // 0: by the size of the launch (lane_budget_for); set by vr_tune or VR_LANE_BUDGET otherwise
@@ -478,7 +478,7 @@ void launch_frame_as(vr_ctx *ctx, const vr::FrameParams &fp, uint32_t *d_out, co
 {
     // one wave per 8x8 tile; a band of 16 rows is two tile rows
     const int tile_waves = ((fp.x1 - fp.x0 + 7) / 8) * 2 * bands_of_part(fp.y1 - fp.y0, fp.part, fp.parts);
-    const int waves_per_block = ctx->waves_per_block;
+    const int waves_per_block = ctx->waves_per_block > 0 ? ctx->waves_per_block : (tile_waves >= 65536 ? 2 : 1);
     const dim3 grid((unsigned)((tile_waves + waves_per_block - 1) / waves_per_block)), block(64 * waves_per_block);
     const vr::VolumeView vol = view_of(ctx);
     const float4 border = make_float4(ctx->border[0], ctx->border[1], ctx->border[2], ctx->border[3]);
