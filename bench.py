@@ -439,6 +439,11 @@ def run_sort_last(args, su):
         cuts = sl.balanced_cuts(counts, cell, nb, grid)
         lo, hi = sl.upload_phantom_box(ctx, n, c["dtype"], grid, box, device, cuts=cuts)
         torch.cuda.empty_cache()
+    lane_budget = None
+    if not args.no_tune:
+        # part of the set-up: the library measures the lane budget of this box's partial march on a view of the orbit
+        ctx.set_camera(*su.camera(45))
+        lane_budget = ctx.tune(w, h)
     t_setup = time.perf_counter() - t_setup
     engine = sl.HipEngine(ctx, w, h)
     fr = sl.SortLastFrame(engine, w, h, rank, world, device, grid=grid, schedule=schedule, host_staging=su.backend != "nccl")
@@ -514,7 +519,7 @@ def run_sort_last(args, su):
                 "name": args.config,
                 "volume": [n, n, n], "image": [w, h], "samples_per_ray": samples,
                 "parallelism": "sort-last x%d (boxes of bricks %dx%dx%d, %s over RCCL, byte-exact re-march of undecided pixels)" % (world, grid[0], grid[1], grid[2], schedule),
-                "bricks_of_rank0": [list(lo), list(hi)], "balance": args.balance if world > 1 else "one box",
+                "bricks_of_rank0": [list(lo), list(hi)], "balance": args.balance if world > 1 else "one box", "lane_budget_rank0": lane_budget,
                 "setup_s": round(t_setup, 2),
             },
             "stages": stages,

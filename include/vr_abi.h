@@ -216,6 +216,8 @@ int vr_march_kernel_times(vr_ctx *ctx, float *ms, int capacity, int *count);
  * -- how long a lane marches its ray before a whole wave takes it over -- and keeps the fastest.
  * Frames are identical for every value; only the time changes with volume, table and image size.
  * Without this call the budget follows the size of the launch (small frames hand rays over early).
+ * On a context that holds a box of a split volume (vr_upload_subvolume_device) the same is done for the
+ * march of vr_render_partial, whose budget is a separate one (part 0 of 1 only).
  * chosen_budget may be NULL.  No counterpart in the reference. */
 int vr_tune(vr_ctx *ctx, int width, int height, int part, int parts, int *chosen_budget);
 

@@ -220,6 +220,25 @@ def test_sub_volume_contexts_refuse_whole_frame_calls(vr, torch, oracle):
     assert vr.subvolume_voxels(24, 24, 24, (0, 1, 3), (1, 3, 4)) == ((0, 6, 22), (7, 23, 24))
 
 
+def test_tune_on_a_box_keeps_its_partial_image(vr, torch, oracle):
+    """vr_tune on a context that holds a box picks the lane budget of the partial march by timing.  The
+    partial image depends on it only in the last bits (which march sums a ray's taps, and the tap at which
+    a dark ray is dropped); a split into bands is refused there."""
+    vox = oracle.phantom(48, np.uint16)
+    ctxs = make_boxes(vr, torch, vox, (2, 1, 1), samples=150)
+    try:
+        c = ctxs[1]
+        c.set_camera(*cf.CAMERAS["h30_v20"])
+        before = c.render_partial(160, 120)
+        assert c.tune(160, 120) in (48, 64, 80, 96, 112, 128, 160)
+        assert np.allclose(c.render_partial(160, 120), before, rtol=2e-6, atol=3e-6)
+        with pytest.raises(vr.VrError):
+            c.tune(160, 120, 0, 2)
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 # ---- several processes on one GPU, exchanges over gloo through host memory ----------------------
 
 def _free_port():

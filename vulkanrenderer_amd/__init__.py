@@ -321,7 +321,8 @@ class VolumeRenderer:
         return (out, st.as_dict()) if stats else out
 
     def tune(self, width, height, part=0, parts=1):
-        """Measures and keeps the fastest per-lane work budget for the current volume, table and camera."""
+        """Measures and keeps the fastest per-lane work budget for the current volume, table and camera
+        (on a context that holds a box of a split volume: the budget of the partial march)."""
         chosen = C.c_int()
         self._check(lib().vr_tune(self._h, width, height, part, parts, C.byref(chosen)))
         return chosen.value

@@ -1324,7 +1324,6 @@ int vr_tune(vr_ctx *ctx, int width, int height, int part, int parts, int *chosen
 {
     if (!ctx) return VR_ERR_ARG;
     if (!ctx->bricks) return fail(ctx, VR_ERR_STATE, "no volume uploaded");
-    if (ctx->sub) return fail(ctx, VR_ERR_STATE, "the context holds a sub-volume");
     if (parts < 1 || part < 0 || part >= parts) return fail(ctx, VR_ERR_ARG, "bad part");
     if (width < 2 || height < 2 || width > 65536 || height > 65536) return fail(ctx, VR_ERR_ARG, "image size out of range");
     if (rows_of_part(height, part, parts) == 0) {   // more parts than bands: this part renders nothing, nothing to measure
@@ -1332,6 +1331,38 @@ int vr_tune(vr_ctx *ctx, int width, int height, int part, int parts, int *chosen
         return VR_OK;
     }
     if (int rc = bind(ctx)) return rc;
+    if (ctx->sub) {
+        // a box of a split volume: the lane march of its partial images has a budget of its own (a box
+        // cannot stop a ray as early as the whole-volume march, and how long its rays are depends on the box)
+        if (part != 0 || parts != 1) return fail(ctx, VR_ERR_ARG, "a box of a split volume renders whole partial images");
+        if (ctx->shading) return fail(ctx, VR_ERR_STATE, "shading is on: the partial march has no lighting");
+        float *d_partial = nullptr;
+        VR_HIP(ctx, hipMalloc(&d_partial, (size_t)width * (size_t)height * vr::kPartial * sizeof(float)));
+        const int before = ctx->partial_budget;
+        int best = before, rc = VR_OK;
+        double best_s = 1.0e300;
+        for (int budget : {48, 64, 80, 96, 112, 128, 160}) {
+            ctx->partial_budget = budget;
+            double fastest = 1.0e300;
+            for (int rep = 0; rep < 3 && rc == VR_OK; rep++) {
+                const auto t0 = std::chrono::steady_clock::now();
+                for (int k = 0; k < 3 && rc == VR_OK; k++) rc = vr_render_partial(ctx, width, height, d_partial, 1);
+                if (rc == VR_OK) rc = vr_synchronize(ctx);
+                const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if (rep > 0 && s < fastest) fastest = s;
+            }
+            if (rc != VR_OK) break;
+            if (fastest < best_s) {
+                best_s = fastest;
+                best = budget;
+            }
+        }
+        ctx->partial_budget = rc == VR_OK ? best : before;
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(d_partial);
+        if (rc == VR_OK && chosen_budget) *chosen_budget = best;
+        return rc;
+    }
     const size_t pixels = (size_t)width * (size_t)rows_of_part(height, part, parts);
     // one allocation, three frames in turn (frames in flight must not share their output)
     const size_t frame_bytes = (pixels * 4 + 255) & ~(size_t)255;
