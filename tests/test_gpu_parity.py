@@ -627,6 +627,28 @@ def test_config3_bands_reassemble(vr, torch):
             for part in range(parts):
                 got[vr.band_row_indices(h, part, parts)] = c.render_bands(w, h, part, parts)
             assert np.array_equal(got, whole), (parts, cf.frame_report(got, whole))
+        # frames in flight at this size (the finishing kernels of a frame run for as long as the next march):
+        # six frames of an orbit back to back into two buffers, nobody waits; the buffers end up with the last
+        # two, and those equal the frames rendered one at a time (tiles longest first) and in mode 2
+        cams = [(math.radians(-140.0 + k), math.radians(20.0)) for k in range(6)]
+        alone = []
+        for cam in cams[-2:]:
+            c.set_camera(*cam)
+            c.set_mode(2)
+            ref = c.render(w, h)
+            c.set_mode(1)
+            one = c.render(w, h)
+            assert np.array_equal(one, ref)
+            alone.append(one)
+        bufs = [torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+        torch.cuda.synchronize()
+        c.set_pipeline(2)
+        for k, cam in enumerate(cams):
+            c.set_camera(*cam)
+            c.render_device(w, h, bufs[k & 1].data_ptr())
+        c.synchronize()
+        c.set_pipeline(1)
+        assert np.array_equal(bufs[0].cpu().numpy(), alone[0]) and np.array_equal(bufs[1].cpu().numpy(), alone[1])
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2])
@@ -946,6 +968,15 @@ def test_two_frames_in_flight_render_the_same_frames(ctx, oracle, torch):
         got.append(pair[k & 1].cpu().numpy().copy())      # .cpu() synchronises torch's stream: the buffer is free again
     for k in range(len(cams)):
         assert np.array_equal(got[k], alone[k]), k
+    # no waits by the caller at all: a frame that writes where a frame still being finished writes waits
+    # for it by itself, so one buffer ends up holding the last frame and two buffers the last two
+    for count in (1, 2):
+        for k, cam in enumerate(cams):
+            ctx.set_camera(*cam)
+            ctx.render_device(w, h, pair[k % count].data_ptr())
+        ctx.synchronize()
+        for k in range(len(cams) - count, len(cams)):
+            assert np.array_equal(pair[k % count].cpu().numpy(), alone[k]), (count, k)
     # a transfer-function change between pipelined frames is ordered after the frames in flight
     ctx.set_camera(*cams[0])
     ctx.render_device(w, h, pair[0].data_ptr())
