@@ -1382,7 +1382,14 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
         e.F0 = F0; e.F1 = F1; e.F2 = F2; e.Tr = Tr;
         e.d[0] = r.d[0]; e.d[1] = r.d[1]; e.d[2] = r.d[2];
         e.tmax = r.tmax; e.step = step; e.pad_ = 0.0f;
-        next_queue[atomicAdd(next_count, 1u)] = e;
+        // one addition for all the rays the wave hands over (additions on one word take their turn), which
+        // also keeps a tile's rays together in the queue
+        const unsigned long long givers = __ballot(true);
+        const int leader = __builtin_ctzll(givers), me = (int)(threadIdx.x & 63);
+        uint32_t first = 0u;
+        if (me == leader) first = atomicAdd(next_count, (uint32_t)__popcll(givers));
+        first = (uint32_t)__builtin_amdgcn_readlane((int)first, leader);
+        next_queue[first + (uint32_t)__popcll(givers & ((1ull << me) - 1ull))] = e;
     } else if (PARTIAL) {
         if (in_rect) {
             float *o = partial_out + (size_t)pixel_id * kPartial;
