@@ -85,3 +85,28 @@ def oracle():
     from oracle import vr_oracle as o
     o.build()
     return o
+
+
+def silhouette_rects(frame, size=128, count=4):
+    """Rectangles of size x size pixels centred on the object's outline in a rendered frame: where a row or
+    a column of the frame goes from background to object."""
+    h, w = frame.shape[:2]
+    lit = frame[..., :3].any(axis=-1)
+    rects = []
+
+    def add(cx, cy):
+        x0 = int(min(max(cx - size // 2, 0), w - size)) & ~7
+        y0 = int(min(max(cy - size // 2, 0), h - size)) & ~7
+        rects.append((x0, y0, x0 + size, y0 + size))
+    for frac in np.linspace(0.3, 0.7, count // 2):
+        row = int(h * frac)
+        cols = np.flatnonzero(lit[row])
+        if cols.size:
+            add(cols[0], row)
+            add(cols[-1], row)
+    col = w // 2
+    rows = np.flatnonzero(lit[:, col])
+    if rows.size:
+        add(col, rows[0])
+        add(col, rows[-1])
+    return rects

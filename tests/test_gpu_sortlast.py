@@ -443,3 +443,229 @@ def test_full_size_split_equals_whole(vr, torch):
     assert want[..., :3].any()
     assert np.array_equal(got, want), cf.frame_report(got, want)
     assert remarched < 0.02 * w * h
+
+
+# ---- the sort-last configuration at its own size: every box of the split resident on one GPU ------------
+
+class BoxesOnOneGpu:
+    """The boxes of an n^3 phantom as separate contexts on one GPU, and the steps of a sort-last frame over
+    them with the buffers kept on the device (4K frames: 1.3 GB of partial images)."""
+
+    def __init__(self, vr, torch, n, grid, samples, balance="even"):
+        from vulkanrenderer_amd import sortlast as sl
+        self.vr, self.torch, self.sl, self.n, self.grid = vr, torch, sl, n, tuple(grid)
+        self.world = grid[0] * grid[1] * grid[2]
+        self.ctxs = []
+        self.cuts = None
+        for r in range(self.world):
+            c = vr.VolumeRenderer(0)
+            self.ctxs.append(c)
+            sl.upload_phantom_box(c, n, 2, self.grid, sl.box_of_rank(r, self.grid), "cuda")
+            torch.cuda.empty_cache()
+            c.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+            c.set_sampling(samples)
+        if balance == "occupied":
+            # what bench.py --balance occupied does over the ranks, here over the contexts: count the occupied
+            # bricks of the even boxes, cut where they balance, load the boxes of that split instead
+            nb = vr.brick_grid(n, n, n)
+            cell = max(1, min(8, min(b // (2 * g) for b, g in zip(nb, self.grid))))
+            counts = sum(sl.occupied_counts(c, nb, cell, "cuda") for c in self.ctxs)
+            self.cuts = sl.balanced_cuts(counts, cell, nb, self.grid)
+            for r, c in enumerate(self.ctxs):
+                sl.upload_phantom_box(c, n, 2, self.grid, sl.box_of_rank(r, self.grid), "cuda", cuts=self.cuts)
+                torch.cuda.empty_cache()
+
+    def close(self):
+        for c in self.ctxs:
+            c.close()
+        self.ctxs = []
+        self.torch.cuda.empty_cache()
+
+    def set_camera(self, cam):
+        for c in self.ctxs:
+            c.set_camera(*cam)
+
+    def partials(self, w, h):
+        torch = self.torch
+        parts = torch.zeros((self.world, w * h, 5), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        for r, c in enumerate(self.ctxs):
+            c.render_partial(w, h, parts[r].data_ptr())
+            c.synchronize()
+        return parts
+
+    def merge(self, parts, w, h, schedule):
+        torch, c0, n = self.torch, self.ctxs[0], w * h
+        if schedule == "direct_send":
+            merged = torch.zeros((n, 5), dtype=torch.float32, device="cuda")
+            slots = torch.arange(self.world, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            c0.composite_ordered(w, h, 0, n, parts.data_ptr(), slots.data_ptr(), self.grid, merged.data_ptr())
+            c0.synchronize()
+            return merged
+        held = {r: parts[r] for r in range(self.world)}
+        for rnd, axis in enumerate(self.sl.swap_rounds(self.world, self.grid)):
+            nxt = {}
+            for r in sorted(held):
+                if r & (1 << rnd):
+                    continue
+                out = torch.empty((n, 5), dtype=torch.float32, device="cuda")
+                torch.cuda.synchronize()
+                c0.composite_pair(w, h, 0, n, held[r].data_ptr(), held[r | (1 << rnd)].data_ptr(), axis, 1, out.data_ptr())
+                c0.synchronize()
+                nxt[r] = out
+            held = nxt
+        return held[0]
+
+    def chain(self, pixels, w, h):
+        """The listed pixels in the shader's own order, the float colour handed from box to box back to front."""
+        torch, m = self.torch, pixels.numel()
+        colour = torch.zeros((m, 4), dtype=torch.float32, device="cuda")
+        for stage in range(self.world):
+            total = torch.zeros((m, 4), dtype=torch.float32, device="cuda")
+            out = torch.empty((m, 4), dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            for r, c in enumerate(self.ctxs):
+                c.chain_stage(w, h, pixels.data_ptr(), m, colour.data_ptr(), out.data_ptr(), stage, self.grid,
+                              self.sl.box_of_rank(r, self.grid))
+                c.synchronize()
+                total += out
+                torch.cuda.synchronize()
+            colour = total
+        return colour
+
+    def frame(self, parts, w, h, schedule):
+        """Steps 2 to 4 on the partial images: the frame (device, uint8 [h, w, 4]) and how many pixels were re-marched."""
+        torch, c0, n = self.torch, self.ctxs[0], w * h
+        merged = self.merge(parts, w, h, schedule)
+        rgba = torch.zeros((n, 4), dtype=torch.uint8, device="cuda")
+        todo = torch.zeros(n, dtype=torch.int32, device="cuda")
+        count = torch.zeros(1, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        c0.decide_partials(w, h, 0, n, merged.data_ptr(), rgba.data_ptr(), todo.data_ptr(), count.data_ptr())
+        c0.synchronize()
+        m = int(count.item())
+        if m:
+            pixels = todo[:m].contiguous()
+            colour = self.chain(pixels, w, h)
+            c0.store_chain(pixels.data_ptr(), colour.data_ptr(), m, 0, n, rgba.data_ptr())
+            c0.synchronize()
+        return rgba.view(h, w, 4), m
+
+    def literal_rect(self, w, h, rect):
+        """Every pixel of the rectangle through the box-to-box chain: the shader's loop order, no early decision."""
+        torch = self.torch
+        x0, y0, x1, y1 = rect
+        ys = torch.arange(y0, y1, dtype=torch.int64, device="cuda").view(-1, 1)
+        xs = torch.arange(x0, x1, dtype=torch.int64, device="cuda").view(1, -1)
+        pixels = (ys * w + xs).reshape(-1).to(torch.int32).contiguous()
+        colour = self.chain(pixels, w, h)
+        out = torch.zeros((w * h, 4), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        self.ctxs[0].store_chain(pixels.data_ptr(), colour.data_ptr(), pixels.numel(), 0, w * h, out.data_ptr())
+        self.ctxs[0].synchronize()
+        return out.view(h, w, 4)[y0:y1, x0:x1].cpu().numpy()
+
+
+def _parity_rects(frame, w, h):
+    """Four rectangles on the object's outline and two inside it (the image centre, where the cut planes of a
+    2x2x2 split cross for the default camera, and one off centre)."""
+    outline = cf.silhouette_rects(frame, size=96, count=4)[:4]
+    inside = [(w // 2 - 48, h // 2 - 48, w // 2 + 48, h // 2 + 48), (w // 2 + 200, h // 2 - 160, w // 2 + 296, h // 2 - 64)]
+    return outline, inside
+
+
+@pytest.mark.parametrize("balance", ["even", "occupied"])
+def test_config5_at_its_own_size(vr, torch, balance):
+    """BASELINE configs[4] as the 8-GPU run holds it: the 4096^3 uint16 phantom in 2x2x2 boxes of bricks (207 GB,
+    all eight resident on this one GPU), 3840x2160, 14188 samples per ray.  The whole volume does not fit beside
+    its boxes, so the frame is checked against the shader's own loop order where that can be had: every pixel of
+    rectangles on the outline and inside the object goes through the box-to-box chain (vr_chain_stage, no early
+    decision, the float colour handed on in the shader's blend order, VolumeRendering.comp:183-202) and must give
+    the bytes of the fast frame; both exchange schedules must give the same frame.  One camera looks along
+    two of the cut planes (rays of the centre row and column run inside them)."""
+    n, w, h = 4096, 3840, 2160
+    samples = int(math.ceil(2 * math.sqrt(3) * n)) - 1
+    assert samples == 14188
+    free, total = torch.cuda.mem_get_info()
+    if total < 250e9:
+        pytest.skip("needs the 288 GB of an MI355X: %.0f GB here" % (total / 1e9))
+    boxes = BoxesOnOneGpu(vr, torch, n, (2, 2, 2), samples, balance=balance)
+    try:
+        if balance == "occupied":
+            lo, hi = boxes.cuts.box((0, 0, 0))
+            print("4096^3 balanced cuts: box (0,0,0) = bricks %s..%s" % (lo, hi))
+        for cam in ((0.0, 0.0), (math.radians(40.0), math.radians(20.0)), (math.radians(-110.0), math.radians(-35.0))):
+            boxes.set_camera(cam)
+            parts = boxes.partials(w, h)
+            direct, remarched = boxes.frame(parts, w, h, "direct_send")
+            swap, remarched_swap = boxes.frame(parts, w, h, "binary_swap")
+            del parts
+            assert torch.equal(direct, swap), cam
+            fast = direct.cpu().numpy()
+            del direct, swap
+            assert fast[..., :3].any() and np.all(fast[..., 3] == 255)
+            assert 0 < remarched < 0.02 * w * h and 0 < remarched_swap < 0.02 * w * h
+            outline, inside = _parity_rects(fast, w, h)
+            assert len(outline) >= 4
+            for kind, rects in (("outline", outline), ("inside", inside)):
+                for rect in rects:
+                    x0, y0, x1, y1 = rect
+                    crop = fast[y0:y1, x0:x1]
+                    lit = crop[..., :3].any(axis=-1)
+                    assert lit.any(), (cam, rect)
+                    if kind == "outline":
+                        assert not lit.all(), (cam, rect)          # object and background
+                    literal = boxes.literal_rect(w, h, rect)
+                    assert np.array_equal(literal, crop), (balance, cam, kind, rect, cf.frame_report(literal, crop))
+            print("4096^3 %s, camera (%.0f, %.0f): %d + %d rectangles equal the chained loop, %d pixels re-marched"
+                  % (balance, math.degrees(cam[0]), math.degrees(cam[1]), len(outline), len(inside), remarched))
+    finally:
+        boxes.close()
+
+
+def test_config5_split_equals_whole_at_3200(vr, torch):
+    """The largest cube whose whole volume and whose eight boxes both fit one GPU (one after the other): 3200^3
+    uint16 at 3840x2160, 11085 samples per ray.  The frame assembled from the boxes (balanced cuts, both exchange
+    schedules; even cuts for one camera) equals the whole-volume vr_render frame byte for byte, all 8.3 M pixels."""
+    n, w, h = 3200, 3840, 2160
+    samples = int(math.ceil(2 * math.sqrt(3) * n)) - 1
+    free, total = torch.cuda.mem_get_info()
+    if total < 250e9:
+        pytest.skip("needs the 288 GB of an MI355X: %.0f GB here" % (total / 1e9))
+    cams = ((math.radians(40.0), math.radians(20.0)), (0.0, 0.0))
+    want = []
+    with vr.VolumeRenderer(0) as c:
+        raw = torch.empty(n ** 3, dtype=torch.int16, device="cuda")
+        torch.cuda.synchronize()
+        c.phantom_generate_device(raw.data_ptr(), 2, n)
+        c.upload_volume_device(raw.data_ptr(), 2, n, n, n)
+        c.synchronize()
+        del raw
+        torch.cuda.empty_cache()
+        c.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+        c.set_sampling(samples)
+        for cam in cams:
+            c.set_camera(*cam)
+            c.set_mode(vr.MODE_FAST)
+            fast = c.render(w, h)
+            c.set_mode(vr.MODE_REFERENCE_SKIP)
+            assert np.array_equal(c.render(w, h), fast), cam
+            want.append(fast)
+    torch.cuda.empty_cache()
+    for balance, use in (("occupied", cams), ("even", cams[:1])):
+        boxes = BoxesOnOneGpu(vr, torch, n, (2, 2, 2), samples, balance=balance)
+        try:
+            for cam in use:
+                boxes.set_camera(cam)
+                parts = boxes.partials(w, h)
+                for schedule in ("direct_send", "binary_swap"):
+                    got, remarched = boxes.frame(parts, w, h, schedule)
+                    got = got.cpu().numpy()
+                    ref = want[cams.index(cam)]
+                    assert ref[..., :3].any()
+                    assert np.array_equal(got, ref), (balance, cam, schedule, cf.frame_report(got, ref))
+                    assert 0 < remarched < 0.02 * w * h
+                del parts
+        finally:
+            boxes.close()
