@@ -34,8 +34,8 @@ extern "C" {
 /* Render strategies.  Both produce the frame the reference shader defines. */
 #define VR_MODE_REFERENCE_ORDER 0 /* back-to-front, every tap (VolumeRendering.comp:183-202) */
 #define VR_MODE_FAST 1            /* front-to-back, macrocell skipping, early termination; for a table under which
-                                     rays do not become opaque (more than a tenth of the pixels of the first frame
-                                     with it undecided) the following frames take VR_MODE_REFERENCE_SKIP's path */
+                                     rays do not become opaque (more than a tenth of the pixels of a whole frame
+                                     undecided) the following frames take VR_MODE_REFERENCE_SKIP's path */
 #define VR_MODE_REFERENCE_SKIP 2  /* back-to-front, taps in exactly transparent bricks not fetched */
 
 typedef struct vr_ctx vr_ctx;
@@ -107,7 +107,11 @@ int vr_histogram(vr_ctx *ctx, float out[100]);
  * points[c] / counts[c]: control graph of channel c (R,G,B,A), sorted by x.  The table lives on
  * the GPU and persists between calls exactly like `transferFunction` (main.cpp:110); entries no
  * segment covers keep their previous value.  reset_state != 0 zeroes it first.  counts[c] == 0
- * leaves channel c untouched. */
+ * leaves channel c untouched.  Meant to be called every frame, as renderCommands does (main.cpp:800-804):
+ * graphs equal to the last call's, which leave every bit of the table as it is, return without touching
+ * the GPU; changed graphs of up to 256 points in all travel with the kernel launch, and the tables the
+ * fast modes skip by are brought up to date on the GPU, for the bricks the change concerns, when the next
+ * frame is rendered.  The host waits for nothing (more than 256 points: one copy it waits for). */
 int vr_set_transfer_function(vr_ctx *ctx, const vr_ctrl_pt *const points[4], const int counts[4], int reset_state);
 int vr_get_lut(vr_ctx *ctx, float out[1024]);
 /* getIntensity, main.cpp:948-953 */
@@ -163,10 +167,10 @@ int vr_render_rect(vr_ctx *ctx, int width, int height, int x0, int y0, int x1, i
  * library runs on until the process ends) instead of buffers allocated on demand, so the frame is limited
  * to VR_STATIC_MAX_PIXELS pixels and 2 * VR_STATIC_MAX_PIXELS / 64 tiles of 8x8 pixels (VR_ERR_ARG
  * beyond).  The call allocates and frees nothing, on the device or through any library; the volume and
- * the transfer function must have been set before (their calls allocate).  The first frame after a change of
- * table, border colour, shading or volume rebuilds the occupancy tables and waits for the stream once.  All
- * contexts on one GPU share that GPU's array: calls that overlap on one GPU, from two contexts or
- * two streams, race. */
+ * the transfer function must have been set before (their calls allocate).  The call enqueues kernels and
+ * memsets only: no copy, no wait (the first frame after a change of table, border colour, shading or volume
+ * rebuilds the occupancy tables on the stream, in front of the march).  All contexts on one GPU share that
+ * GPU's array: calls that overlap on one GPU, from two contexts or two streams, race. */
 #define VR_STATIC_MAX_PIXELS (1280 * 720) /* the reference's window, main.cpp:30 */
 int vr_render_static(vr_ctx *ctx, int width, int height, uint8_t *d_out);
 int vr_static_max_pixels(void);

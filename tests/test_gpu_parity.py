@@ -1008,3 +1008,122 @@ def test_eight_pipelined_contexts_in_one_process(vr, oracle, torch):
     finally:
         for c in ctxs:
             c.close()
+
+
+# ---- the table set every frame, as the reference's frame loop does (main.cpp:800-804, 687-736) ---------------
+
+def test_unchanged_table_call_costs_nothing_and_changes_nothing(ctx, oracle, torch):
+    """renderCommands rebuilds and uploads the table every frame whether or not a control point moved.  The same
+    graphs again leave every bit of the table as it is, so the call must neither touch the table nor disturb the
+    frames in flight; with reset_state it still zeroes what the graphs do not cover when the table is not already
+    what they make of a zeroed one."""
+    vox = oracle.phantom(64, np.uint16)
+    ctx.upload_volume(vox)
+    frac = [[(100.0, 0.2), (300.0, 0.8)]] * 3 + [[(150.0, 0.0), (300.0, 0.7)]]    # entries below the first point are not covered
+    ctx.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+    ctx.update_transfer_function(frac, reset_state=False)             # stale entries of the first table survive
+    lut = np.zeros((256, 4), np.float32)
+    oracle.lut_update(lut, cf.TF_GRAPHS)
+    oracle.lut_update(lut, frac)
+    assert cf.same_bits(ctx.transfer_function(), lut)
+    ctx.update_transfer_function(frac, reset_state=False)             # same graphs: nothing changes
+    assert cf.same_bits(ctx.transfer_function(), lut)
+    ctx.update_transfer_function(frac, reset_state=True)              # same graphs, but now from a zeroed table
+    lut0 = np.zeros((256, 4), np.float32)
+    oracle.lut_update(lut0, frac)
+    assert cf.same_bits(ctx.transfer_function(), lut0) and not cf.same_bits(lut0, lut)
+    ctx.update_transfer_function(frac, reset_state=True)
+    ctx.update_transfer_function(frac, reset_state=False)
+    assert cf.same_bits(ctx.transfer_function(), lut0)
+    # pipelined frames with the call in front of each: same frames as without it
+    w, h, samples = 200, 150, 220
+    ctx.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+    ctx.set_sampling(samples, (0, 0, 0, 0))
+    ctx.set_mode(1)
+    cams = [(math.radians(-60.0 + 7 * k), math.radians(15.0)) for k in range(6)]
+    want = []
+    for cam in cams:
+        ctx.set_camera(*cam)
+        want.append(ctx.render(w, h))
+    bufs = [torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda") for _ in cams]
+    torch.cuda.synchronize()
+    ctx.set_pipeline(2)
+    for cam, buf in zip(cams, bufs):
+        ctx.update_transfer_function(cf.TF_GRAPHS, reset_state=False)
+        ctx.set_camera(*cam)
+        ctx.render_device(w, h, buf.data_ptr())
+    ctx.synchronize()
+    ctx.set_pipeline(1)
+    for k in range(len(cams)):
+        assert np.array_equal(bufs[k].cpu().numpy(), want[k]), k
+
+
+def _moving_tables():
+    """Tables of an edited control graph: the alpha threshold moves up and down (the set of transparent entries
+    changes both ways), a colour changes alone (it does not), alpha moves between non-zero values (it does not)."""
+    xs = (0.0, 120.0, 300.0, 483.0)
+    tables = []
+    for thr in (120.0, 160.0, 90.0, 40.0, 200.0, 120.0):
+        ax = (0.0, thr, 300.0, 483.0)
+        tables.append([list(zip(xs, (0, .9, 1, 1))), list(zip(xs, (0, .3, .8, 1))), list(zip(xs, (0, .1, .5, 1))),
+                       list(zip(ax, (0, 0, .05, .6)))])
+    tables.append([list(zip(xs, (0, .2, .4, 1))), list(zip(xs, (0, .9, .8, 1))), list(zip(xs, (0, .1, .9, .3))), list(zip(xs, (0, 0, .05, .6)))])
+    tables.append([list(zip(xs, (0, .2, .4, 1))), list(zip(xs, (0, .9, .8, 1))), list(zip(xs, (0, .1, .9, .3))), list(zip(xs, (0, 0, .3, .9)))])
+    return tables
+
+
+def test_table_changed_between_frames(ctx, oracle, torch):
+    """A control point dragged from frame to frame: every frame equals the checker's frame for its table, in the
+    fast mode and in the skipping mode (both rely on occupancy tables rebuilt on the GPU after each change, only
+    for the bricks the change concerns), one frame at a time and with frames in flight."""
+    vox = oracle.phantom(80, np.uint16)
+    vol, _ = oracle.normalize(vox)
+    w, h, samples = 160, 120, 277
+    ctx.upload_volume(vox)
+    ctx.set_sampling(samples, (0, 0, 0, 0))
+    cam = cf.CAMERAS["h30_v20"]
+    ctx.set_camera(*cam)
+    vp, m = oracle.camera(cam[0], cam[1], w, h)
+    tables = _moving_tables()
+    lut = np.zeros((256, 4), np.float32)
+    want = []
+    ctx.update_transfer_function(tables[0], reset_state=True)
+    for k, graphs in enumerate(tables):
+        oracle.lut_update(lut, graphs)
+        want.append(oracle.render(vol, lut, vp[4:8], m, w, h, samples))
+        ctx.update_transfer_function(graphs, reset_state=False)
+        for mode in (1, 2, 0):
+            ctx.set_mode(mode)
+            got = ctx.render(w, h)
+            assert np.array_equal(got, want[k]), (k, mode, cf.frame_report(got, want[k]))
+    assert any(not np.array_equal(want[k], want[k + 1]) for k in range(len(want) - 1))
+    # the same walk with frames in flight, the table set in front of every frame, nobody waits in between
+    ctx.update_transfer_function(tables[0], reset_state=True)
+    bufs = [torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda") for _ in tables]
+    torch.cuda.synchronize()
+    ctx.set_mode(1)
+    ctx.set_pipeline(2)
+    for graphs, buf in zip(tables, bufs):
+        ctx.update_transfer_function(graphs, reset_state=False)
+        ctx.render_device(w, h, buf.data_ptr())
+    ctx.synchronize()
+    ctx.set_pipeline(1)
+    for k in range(len(tables)):
+        got = bufs[k].cpu().numpy()
+        assert np.array_equal(got, want[k]), (k, cf.frame_report(got, want[k]))
+    # border colour and lighting change what the decisions rely on without a new table
+    ctx.set_sampling(samples, (0.1, 0.2, 0.3, 0.5))
+    got = ctx.render(w, h)
+    assert np.array_equal(got, oracle.render(vol, lut, vp[4:8], m, w, h, samples, border=(0.1, 0.2, 0.3, 0.5)))
+    ctx.set_sampling(samples, (0, 0, 0, 0))
+    assert np.array_equal(ctx.render(w, h), want[-1])
+
+
+def test_many_control_points_take_the_staged_path(ctx, oracle):
+    """More points than travel with the launch (256): the graphs go through the staging buffer; same table."""
+    xs = np.linspace(0.0, 480.0, 300)
+    graphs = [[(float(x), float((k * 37 + i * 11) % 101) / 100.0) for k, x in enumerate(xs)] for i in range(4)]
+    ctx.update_transfer_function(graphs, reset_state=True)
+    lut = np.zeros((256, 4), np.float32)
+    oracle.lut_update(lut, graphs)
+    assert cf.same_bits(ctx.transfer_function(), lut)

@@ -2,6 +2,7 @@
 
 Collected last on purpose (the file name sorts behind the other tests)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -29,6 +30,7 @@ def test_static_scratch_frames_equal_vr_render():
         ctx.set_mode(vr.MODE_REFERENCE_ORDER)      # the static entry point marches fast whatever mode is set
         # two calls in a row, the second with a smaller frame and another camera: what the first left in
         # the shared scratch (queues, tile ranges, counters) must not leak into the second
+        big_probe = torch.zeros((700, 1000, 4), dtype=torch.uint8, device="cuda")
         for (w, h), cam in (((640, 360), cf.CAMERAS["h30_v20"]), ((200, 150), cf.CAMERAS["hm135_vm60"])):
             ctx.set_camera(*cam)
             want = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
@@ -37,13 +39,32 @@ def test_static_scratch_frames_equal_vr_render():
             ctx.set_mode(vr.MODE_FAST)
             ctx.render_device(w, h, want.data_ptr())
             ctx.set_mode(vr.MODE_REFERENCE_ORDER)
-            ctx.render_static(w, h, got.data_ptr())
+            # the promise itself: while every allocation and release of the library is refused (and counted)
+            # the call still succeeds, and the GPU's free memory is what it was
             ctx.synchronize()
+            torch.cuda.synchronize()
+            free_before = torch.cuda.mem_get_info()[0]
+            os.environ["VR_TEST_FORBID_ALLOC"] = "1"
+            try:
+                ctx.render_static(w, h, got.data_ptr())
+                ctx.render_static(w, h, got.data_ptr())
+                ctx.synchronize()
+            finally:
+                del os.environ["VR_TEST_FORBID_ALLOC"]
+            assert torch.cuda.mem_get_info()[0] == free_before, (w, h)
             assert np.array_equal(got.cpu().numpy(), want.cpu().numpy()), (w, h)
             # and both are the checker's frame
             vp, m = o.camera(cam[0], cam[1], w, h)
             ref = o.render(vol, lut, vp[4:8], m, w, h, samples)
             assert np.array_equal(got.cpu().numpy(), ref), (w, h)
+        # the hook itself: vr_render's buffers for a frame size it has not seen are allocated on demand, and refused
+        os.environ["VR_TEST_FORBID_ALLOC"] = "1"
+        try:
+            ctx.set_mode(vr.MODE_FAST)
+            with pytest.raises(vr.VrError):
+                ctx.render_device(1000, 700, big_probe.data_ptr())
+        finally:
+            del os.environ["VR_TEST_FORBID_ALLOC"]
         # a second context on the same GPU uses the same array (one after the other: fine)
         with vr.VolumeRenderer(0) as other:
             other.upload_volume(vox)

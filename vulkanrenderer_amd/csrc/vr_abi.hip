@@ -43,19 +43,33 @@ struct vr_ctx {
     int *occ = nullptr;                   // bounding box of the occupied bricks (6 ints)
     uint32_t *skip = nullptr;             // per brick: 2-bit code of the coarsest empty cube around it
     uint32_t *occ_list = nullptr;         // indices of the occupied bricks, for the per-tile depth ranges
-    uint32_t *d_occ_count = nullptr;
-    uint32_t occ_count = 0;
+    uint32_t *d_occ_count = nullptr;      // its length; stays on the device (k_splat_bricks reads it there)
     uint2 *tiles = nullptr;               // per 8x8 pixel tile: depth range of the occupied bricks (fast mode)
     size_t tiles_cap = 0;
     bool tile_clip = true;
     bool occupancy_dirty = true;
+    bool occupancy_force = true;          // the next refresh rebuilds every occupancy table whatever the table says (new volume)
+    hipEvent_t occ_ready = nullptr;       // recorded behind a refresh: the stream the depth ranges are built on waits for it
     // Fast mode pays off when rays become opaque or leave the object early.  With a table of low alpha
     // everywhere neither happens: every tap is marched, the rounding bound of the decision grows with the
     // number of taps blended, and the undecided rays are marched a second and third time by the replay.
-    // The first fast frame after a change of table, border, shading, sampling or volume is therefore a
-    // probe: if more than a tenth of its pixels had to be replayed, fast frames are rendered by the skipping
-    // reference-order march (same bytes, every tap once) until the next such change.
-    bool fast_probe = true, fast_fallback = false;
+    // Every fast frame that covers the whole image therefore reports, through a word of page-locked host
+    // memory its last kernel writes, how many of its rays went through the replay.  The host looks at the
+    // word when it next renders (it never waits for it): with more than a tenth of the pixels replayed, fast
+    // frames are rendered by the skipping reference-order march (same bytes, every tap once) until table,
+    // border, shading, sampling or volume change, with one fast frame in every kFallbackRetry to look again
+    // (the view may have changed).
+    bool fast_fallback = false;
+    static constexpr int kFallbackRetry = 128;
+    int fallback_frames = 0;
+    unsigned long long *probe_word = nullptr;   // host, page-locked: frame sequence number << 32 | replayed rays
+    unsigned long long *probe_dev = nullptr;    // the same word as the device addresses it
+    uint32_t frame_seq = 0, probe_seen = 0, table_epoch = 0;
+    struct ProbeMeta {
+        uint32_t seq, epoch;
+        size_t pixels;
+        bool eligible;
+    } probe_meta[8] = {};
     int dtype = 0, nx = 0, ny = 0, nz = 0, nbx = 0, nby = 0, nbz = 0;
     // sort-last: the bricks held are the box [brick_lo, brick_lo + (nbx, nby, nbz)) of the volume's grid
     bool sub = false;
@@ -66,6 +80,13 @@ struct vr_ctx {
     float *lut = nullptr;  // 256 x RGBA on the device, persists like `transferFunction`
     vr::CtrlPt *d_pts = nullptr;
     size_t d_pts_cap = 0;
+    // The graphs of the last call and whether the table is what they make of a zeroed table.  The builder
+    // writes values that depend on the graphs alone into entries that depend on the graphs alone, so the same
+    // graphs applied again leave every bit of the table as it is: such a call (the reference makes one every
+    // frame, main.cpp:800-804) returns without touching the GPU.
+    std::vector<vr::CtrlPt> last_pts;
+    int last_offs[5] = {0, 0, 0, 0, 0};
+    bool table_from_zero = true;
     float border[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 
     // camera
@@ -187,6 +208,35 @@ int fail(vr_ctx *ctx, int code, const std::string &msg)
             return fail((ctx), VR_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));         \
     } while (0)
 
+// Every device allocation and release of the library goes through these two.  Test hook: while the
+// environment variable VR_TEST_FORBID_ALLOC is set to a non-zero number they refuse and count the attempt,
+// so that a test can show that an entry point which promises not to allocate does not.
+unsigned long long g_forbidden_calls = 0;
+bool alloc_forbidden()
+{
+    const char *e = std::getenv("VR_TEST_FORBID_ALLOC");
+    return e && std::atoi(e) != 0;
+}
+template <typename P>
+hipError_t dev_alloc(P **ptr, size_t bytes)
+{
+    if (alloc_forbidden()) {
+        g_forbidden_calls++;
+        *ptr = nullptr;
+        return hipErrorOutOfMemory;
+    }
+    return hipMalloc(ptr, bytes);
+}
+template <typename P>
+hipError_t dev_free(P *ptr)
+{
+    if (alloc_forbidden()) {
+        g_forbidden_calls++;
+        return hipErrorInvalidValue;
+    }
+    return hipFree(ptr);
+}
+
 // Device allocation of a volume upload; honours the context's test hook.
 template <typename P>
 hipError_t volume_alloc(vr_ctx *ctx, P **ptr, size_t bytes)
@@ -195,7 +245,7 @@ hipError_t volume_alloc(vr_ctx *ctx, P **ptr, size_t bytes)
         *ptr = nullptr;
         return hipErrorOutOfMemory;
     }
-    return hipMalloc(ptr, bytes);
+    return dev_alloc(ptr, bytes);
 }
 
 int bind(vr_ctx *ctx)
@@ -218,24 +268,24 @@ void drain(vr_ctx *ctx)
 void release_volume(vr_ctx *ctx)
 {
     drain(ctx);
-    if (ctx->bricks) (void)hipFree(ctx->bricks);
-    if (ctx->cells) (void)hipFree(ctx->cells);
-    if (ctx->touched) (void)hipFree(ctx->touched);
+    if (ctx->bricks) (void)dev_free(ctx->bricks);
+    if (ctx->cells) (void)dev_free(ctx->cells);
+    if (ctx->touched) (void)dev_free(ctx->touched);
     for (int l = 0; l < vr::kLevels; l++) {
-        if (ctx->empty[l]) (void)hipFree(ctx->empty[l]);
+        if (ctx->empty[l]) (void)dev_free(ctx->empty[l]);
         ctx->empty[l] = nullptr;
     }
-    if (ctx->micro) (void)hipFree(ctx->micro);
-    if (ctx->skip) (void)hipFree(ctx->skip);
-    if (ctx->occ_list) (void)hipFree(ctx->occ_list);
+    if (ctx->micro) (void)dev_free(ctx->micro);
+    if (ctx->skip) (void)dev_free(ctx->skip);
+    if (ctx->occ_list) (void)dev_free(ctx->occ_list);
     ctx->micro = nullptr;
     ctx->skip = nullptr;
     ctx->occ_list = nullptr;
-    ctx->occ_count = 0;
     ctx->bricks = nullptr;
     ctx->cells = nullptr;
     ctx->touched = nullptr;
     ctx->occupancy_dirty = true;
+    ctx->occupancy_force = true;
     ctx->brick_count = 0;
     ctx->dtype = 0;
     ctx->sub = false;
@@ -309,7 +359,7 @@ int ingest_device(vr_ctx *ctx, T *d_raw, int nx, int ny, int nz, float max_value
     uint32_t data_max = 0;
     if (count > 0) {
         uint32_t *d_max = nullptr;
-        VR_HIP(ctx, hipMalloc(&d_max, sizeof(uint32_t)));
+        VR_HIP(ctx, dev_alloc(&d_max, sizeof(uint32_t)));
         VR_HIP(ctx, hipMemsetAsync(d_max, 0, sizeof(uint32_t), ctx->stream));
         const int blocks = (int)std::min<size_t>((count + 255) / 256, 256 * 16);
         if (big_endian)
@@ -318,7 +368,7 @@ int ingest_device(vr_ctx *ctx, T *d_raw, int nx, int ny, int nz, float max_value
             hipLaunchKernelGGL((vr::k_swap_max<T, false>), dim3(blocks), dim3(256), 0, ctx->stream, d_raw, count, d_max);
         VR_HIP(ctx, hipMemcpyAsync(&data_max, d_max, sizeof data_max, hipMemcpyDeviceToHost, ctx->stream));
         VR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        (void)hipFree(d_max);
+        (void)dev_free(d_max);
     }
 
     float mx = (float)data_max;  // main.cpp:144, exact for 16-bit values
@@ -374,6 +424,9 @@ int ingest_device(vr_ctx *ctx, T *d_raw, int nx, int ny, int nz, float max_value
         return fail(ctx, VR_ERR_HIP, std::string("volume upload: ") + hipGetErrorString(err));
     }
     ctx->occupancy_dirty = true;
+    ctx->occupancy_force = true;
+    ctx->table_epoch++;
+    ctx->fast_fallback = false;
     return VR_OK;
 }
 
@@ -384,49 +437,67 @@ int check_dims(vr_ctx *ctx, int dtype, int nx, int ny, int nz)
     return VR_OK;
 }
 
-// Brings the occupancy bits up to date with the current table, border colour and volume.
+// Brings the occupancy tables up to date with the current table, border colour and volume.  Nothing here
+// waits for the GPU: k_lut_derive compares the table with the one the occupancy tables were built for and
+// leaves the verdict in device memory, where the kernels enqueued behind it read it; when the set of
+// transparent entries is what it was (a colour changed, an alpha moved between non-zero values, lighting
+// was switched) they return at once.
 int refresh_occupancy(vr_ctx *ctx)
 {
     if (!ctx->occupancy_dirty) return VR_OK;
     drain(ctx);   // frames still being finished read the tables rebuilt here
     const float4 border = make_float4(ctx->border[0], ctx->border[1], ctx->border[2], ctx->border[3]);
     hipLaunchKernelGGL(vr::k_lut_derive, dim3(1), dim3(256), 0, ctx->stream, reinterpret_cast<const float4 *>(ctx->lut), border,
-                       ctx->shading ? vr::shade_bound(ctx->scene) : 0.0f, ctx->lut_info);
+                       ctx->shading ? vr::shade_bound(ctx->scene) : 0.0f, ctx->occupancy_force ? 1 : 0, ctx->lut_info, ctx->occ,
+                       ctx->d_occ_count);
     const unsigned bricks = (unsigned)ctx->brick_count;
     hipLaunchKernelGGL(vr::k_classify_bricks, dim3((bricks + 255) / 256), dim3(256), 0, ctx->stream, ctx->cells, bricks, ctx->inv_hi,
                        ctx->inv_lo, ctx->lut_info, ctx->empty[0]);
     for (int l = 1; l < vr::kLevels; l++) {
         const unsigned cubes = (unsigned)(ctx->lx[l] * ctx->ly[l] * ctx->lz[l]);
-        hipLaunchKernelGGL(vr::k_classify_up, dim3((cubes + 255) / 256), dim3(256), 0, ctx->stream, ctx->empty[l - 1], ctx->lx[l - 1],
-                           ctx->ly[l - 1], ctx->lz[l - 1], ctx->lx[l], ctx->ly[l], ctx->lz[l], ctx->empty[l]);
+        hipLaunchKernelGGL(vr::k_classify_up, dim3((cubes + 255) / 256), dim3(256), 0, ctx->stream, ctx->lut_info, ctx->empty[l - 1],
+                           ctx->lx[l - 1], ctx->ly[l - 1], ctx->lz[l - 1], ctx->lx[l], ctx->ly[l], ctx->lz[l], ctx->empty[l]);
     }
-    // empty box: lo = INT_MAX, hi = -1
-    VR_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)ctx->occ, 0x7fffffff, 3, ctx->stream));
-    VR_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)(ctx->occ + 3), -1, 3, ctx->stream));
-    hipLaunchKernelGGL(vr::k_occupied_bounds, dim3(1024), dim3(256), 0, ctx->stream, ctx->empty[0], ctx->lx[0], ctx->ly[0], ctx->lz[0],
-                       ctx->occ);
+    hipLaunchKernelGGL(vr::k_occupied_bounds, dim3(1024), dim3(256), 0, ctx->stream, ctx->lut_info, ctx->empty[0], ctx->lx[0], ctx->ly[0],
+                       ctx->lz[0], ctx->occ);
     const unsigned skip_words = (bricks + 15) / 16;
-    hipLaunchKernelGGL(vr::k_pack_skip, dim3((skip_words + 255) / 256), dim3(256), 0, ctx->stream, ctx->empty[0], ctx->empty[1],
-                       ctx->empty[2], ctx->lx[0], ctx->ly[0], ctx->lz[0], ctx->lx[1], ctx->ly[1], ctx->lx[2], ctx->ly[2], ctx->skip);
-    const unsigned micro_blocks =(unsigned)std::min<size_t>((ctx->brick_count + 3) / 4, 1u << 18);
+    hipLaunchKernelGGL(vr::k_pack_skip, dim3((skip_words + 255) / 256), dim3(256), 0, ctx->stream, ctx->lut_info, ctx->empty[0],
+                       ctx->empty[1], ctx->empty[2], ctx->lx[0], ctx->ly[0], ctx->lz[0], ctx->lx[1], ctx->ly[1], ctx->lx[2], ctx->ly[2],
+                       ctx->skip);
+    const unsigned micro_blocks = (unsigned)std::min<size_t>((ctx->brick_count + 3) / 4, 1u << 18);
     if (ctx->dtype == VR_DTYPE_U8)
         hipLaunchKernelGGL((vr::k_classify_micro<uint8_t>), dim3(micro_blocks), dim3(256), 0, ctx->stream, (const uint8_t *)ctx->bricks,
-                           ctx->empty[0], bricks, ctx->inv_hi, ctx->inv_lo, ctx->lut_info, ctx->micro);
+                           ctx->empty[0], ctx->cells, bricks, ctx->inv_hi, ctx->inv_lo, ctx->lut_info, ctx->micro);
     else
         hipLaunchKernelGGL((vr::k_classify_micro<uint16_t>), dim3(micro_blocks), dim3(256), 0, ctx->stream, (const uint16_t *)ctx->bricks,
-                           ctx->empty[0], bricks, ctx->inv_hi, ctx->inv_lo, ctx->lut_info, ctx->micro);
-    VR_HIP(ctx, hipMemsetAsync(ctx->d_occ_count, 0, sizeof(uint32_t), ctx->stream));
+                           ctx->empty[0], ctx->cells, bricks, ctx->inv_hi, ctx->inv_lo, ctx->lut_info, ctx->micro);
     const unsigned cubes4 = (unsigned)(((ctx->lx[0] + 3) / 4) * ((ctx->ly[0] + 3) / 4) * ((ctx->lz[0] + 3) / 4));
-    hipLaunchKernelGGL(vr::k_list_occupied, dim3((cubes4 + 3) / 4), dim3(256), 0, ctx->stream, ctx->empty[0], ctx->lx[0], ctx->ly[0],
-                       ctx->lz[0], ctx->occ_list, ctx->d_occ_count);
+    hipLaunchKernelGGL(vr::k_list_occupied, dim3((cubes4 + 3) / 4), dim3(256), 0, ctx->stream, ctx->lut_info, ctx->empty[0], ctx->lx[0],
+                       ctx->ly[0], ctx->lz[0], ctx->occ_list, ctx->d_occ_count);
     VR_HIP(ctx, hipGetLastError());
-    VR_HIP(ctx, hipMemcpyAsync(&ctx->occ_count, ctx->d_occ_count, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    VR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    VR_HIP(ctx, hipEventRecord(ctx->occ_ready, ctx->stream));
     ctx->occupancy_dirty = false;
-    ctx->fast_probe = true;
-    ctx->fast_fallback = false;
+    ctx->occupancy_force = false;
     return VR_OK;
 }
+
+// What the last finished fast frame reported (see vr_ctx::fast_fallback).  Reads host memory only.
+void poll_probe(vr_ctx *ctx)
+{
+    const unsigned long long w = __atomic_load_n(ctx->probe_word, __ATOMIC_ACQUIRE);
+    const uint32_t seq = (uint32_t)(w >> 32);
+    if (seq == 0u || seq == ctx->probe_seen) return;
+    ctx->probe_seen = seq;
+    const vr_ctx::ProbeMeta &m = ctx->probe_meta[seq & 7u];
+    if (m.seq != seq || m.epoch != ctx->table_epoch || !m.eligible) return;
+    const bool translucent = (size_t)(w & 0xffffffffull) * 10u > m.pixels;
+    if (translucent && !ctx->fast_fallback) ctx->fallback_frames = 0;
+    ctx->fast_fallback = translucent;
+}
+
+// Number of blocks k_splat_bricks is launched with: enough for the longest list of surface bricks the
+// volume can have, capped (a block takes several runs of the list in turn).
+unsigned splat_blocks(const vr_ctx *ctx) { return (unsigned)std::min<size_t>((ctx->brick_count + 255) / 256, 4096); }
 
 // Sort-first split of `rows` image rows into 16-row bands dealt round-robin to `parts` parts.
 int bands_of_part(int rows, int part, int parts)
@@ -457,6 +528,7 @@ struct FrameBuffers {
     bool may_order;          // the frame may use (and allocate) the context's tile-order lists
     bool clear_after;        // clear the counters behind the frame's last kernel
     int set;                 // which of the two sets of per-frame buffers this is
+    uint32_t seq;            // the frame's sequence number, for its report to the host (k_finish_frame)
 };
 
 // The lane budget when neither vr_tune nor the environment has set one.  The lane march is one wave per
@@ -500,11 +572,12 @@ void launch_frame_as(vr_ctx *ctx, const vr::FrameParams &fp, uint32_t *d_out, co
         const int tile_px = 1 << vr::kRangeShift;
         const int tiles_x = (fp.width + tile_px - 1) / tile_px, tiles_y = (fp.height + tile_px - 1) / tile_px;
         const uint2 *tiles = nullptr;
-        if (ctx->tile_clip && fb.tiles && ctx->occ_count > 0) {
+        if (ctx->tile_clip && fb.tiles) {
             hipStream_t ps = fb.prep ? fb.prep : s;
             if (fb.prep && fb.ranges_free) (void)hipStreamWaitEvent(ps, fb.ranges_free, 0);
+            if (fb.prep) (void)hipStreamWaitEvent(ps, ctx->occ_ready, 0);   // the list of surface bricks may just have been rebuilt
             (void)hipMemsetAsync(fb.tiles, 0, ((size_t)tiles_x * tiles_y + 1) * sizeof(uint2), ps);   // + the word that switches the ranges off
-            hipLaunchKernelGGL(vr::k_splat_bricks, dim3((ctx->occ_count + 255) / 256), dim3(256), 0, ps, vol, fp, ctx->occ_list, ctx->occ_count,
+            hipLaunchKernelGGL(vr::k_splat_bricks, dim3(splat_blocks(ctx)), dim3(256), 0, ps, vol, fp, ctx->occ_list, ctx->d_occ_count,
                                fb.tiles, tiles_x, tiles_y, fb.counters);
             if (fb.prep) {
                 (void)hipEventRecord(fb.ranges_done, ps);
@@ -521,8 +594,8 @@ void launch_frame_as(vr_ctx *ctx, const vr::FrameParams &fp, uint32_t *d_out, co
         if (!STATS && fb.may_order && ctx->tile_order && tile_waves >= 8192) {
             if ((size_t)tile_waves > ctx->order_cap) {
                 for (int k = 0; k < vr_ctx::kSets; k++) {
-                    if (ctx->order_lists[k]) (void)hipFree(ctx->order_lists[k]);
-                    if (ctx->tile_ticks[k]) (void)hipFree(ctx->tile_ticks[k]);
+                    if (ctx->order_lists[k]) (void)dev_free(ctx->order_lists[k]);
+                    if (ctx->tile_ticks[k]) (void)dev_free(ctx->tile_ticks[k]);
                     ctx->order_lists[k] = ctx->tile_ticks[k] = nullptr;
                     ctx->order_valid[k] = false;
                 }
@@ -530,8 +603,8 @@ void launch_frame_as(vr_ctx *ctx, const vr::FrameParams &fp, uint32_t *d_out, co
                 const size_t words = (size_t)vr::kOrderLists + (size_t)vr::kOrderBuckets * (size_t)tile_waves;
                 bool ok = true;
                 for (int k = 0; k < vr_ctx::kSets && ok; k++)
-                    ok = hipMalloc(&ctx->order_lists[k], words * sizeof(uint32_t)) == hipSuccess &&
-                         hipMalloc(&ctx->tile_ticks[k], (size_t)tile_waves * sizeof(uint32_t)) == hipSuccess;
+                    ok = dev_alloc(&ctx->order_lists[k], words * sizeof(uint32_t)) == hipSuccess &&
+                         dev_alloc(&ctx->tile_ticks[k], (size_t)tile_waves * sizeof(uint32_t)) == hipSuccess;
                 if (ok) ctx->order_cap = (size_t)tile_waves;
                 else (void)hipGetLastError();   // no lists: launch order
             }
@@ -562,7 +635,7 @@ void launch_frame_as(vr_ctx *ctx, const vr::FrameParams &fp, uint32_t *d_out, co
         else
             hipLaunchKernelGGL((vr::k_march_long<T, 64, STATS, SHADE>), replay_grid, dim3(256), 0, ts, vol, fp, lut, border, ctx->lut_info, d_out, fb.counters, ctx->touched, fb.queue, fb.long_queue);
         hipLaunchKernelGGL((vr::k_replay_exact<T, STATS, SHADE>), replay_grid, dim3(256), 0, ts, vol, fp, lut, border, ctx->lut_info, d_out, fb.counters, ctx->touched, fb.queue, tiles, tiles_x);
-        if (fb.clear_after) (void)hipMemsetAsync(fb.counters, 0, offsetof(vr::Counters, lut_error), ts);
+        hipLaunchKernelGGL(vr::k_finish_frame, dim3(1), dim3(64), 0, ts, fb.counters, ctx->probe_dev, fb.seq, fb.clear_after ? 1 : 0);
         if (order_out) {
             // behind the frame's last kernel: the march before it has read these lists, and the next reader is
             // the march of the next frame on this set of buffers, which waits for this set's last kernels
@@ -599,17 +672,23 @@ int vr_create(int device, vr_ctx **out)
     ctx->device = device;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
-        hipMalloc(&ctx->lut, 1024 * sizeof(float)) != hipSuccess ||
-        hipMalloc(&ctx->counters, sizeof(vr::Counters)) != hipSuccess ||
-        hipMalloc(&ctx->lut_info, sizeof(vr::LutInfo)) != hipSuccess ||
-        hipMalloc(&ctx->occ, 6 * sizeof(int)) != hipSuccess ||
-        hipMalloc(&ctx->d_occ_count, sizeof(uint32_t)) != hipSuccess ||
+        dev_alloc(&ctx->lut, 1024 * sizeof(float)) != hipSuccess ||
+        dev_alloc(&ctx->counters, sizeof(vr::Counters)) != hipSuccess ||
+        dev_alloc(&ctx->lut_info, sizeof(vr::LutInfo)) != hipSuccess ||
+        dev_alloc(&ctx->occ, 6 * sizeof(int)) != hipSuccess ||
+        dev_alloc(&ctx->d_occ_count, sizeof(uint32_t)) != hipSuccess ||
+        hipMemset(ctx->d_occ_count, 0, sizeof(uint32_t)) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->occ_ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventRecord(ctx->occ_ready, ctx->stream) != hipSuccess ||
+        hipHostMalloc((void **)&ctx->probe_word, 64, hipHostMallocDefault) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&ctx->probe_dev, ctx->probe_word, 0) != hipSuccess ||
         hipMemset(ctx->lut, 0, 1024 * sizeof(float)) != hipSuccess ||  // main.cpp:110: zero-initialised table
         hipMemset(ctx->counters, 0, sizeof(vr::Counters)) != hipSuccess ||
         hipMemcpyToSymbol(HIP_SYMBOL(vr::d_phantom), vr::PHANTOM, sizeof(vr::PHANTOM)) != hipSuccess) {
         vr_destroy(ctx);
         return VR_ERR_HIP;
     }
+    *ctx->probe_word = 0ull;
     if (const char *e = std::getenv("VR_TEST_FAIL_ALLOC")) ctx->fail_alloc_in = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("VR_TILE_CLIP")) ctx->tile_clip = std::atoi(e) != 0;
     if (const char *e = std::getenv("VR_TILE_ORDER")) {
@@ -651,12 +730,12 @@ int vr_destroy(vr_ctx *ctx)
     for (int k = 0; k < vr_ctx::kSets; k++) ctx->tail_busy[k] = false;
     release_volume(ctx);
     for (int k = 0; k < vr_ctx::kSets - 1; k++) {
-        if (ctx->counters_alt[k]) (void)hipFree(ctx->counters_alt[k]);
-        if (ctx->queue_alt[k]) (void)hipFree(ctx->queue_alt[k]);
-        if (ctx->long_alt[k]) (void)hipFree(ctx->long_alt[k]);
+        if (ctx->counters_alt[k]) (void)dev_free(ctx->counters_alt[k]);
+        if (ctx->queue_alt[k]) (void)dev_free(ctx->queue_alt[k]);
+        if (ctx->long_alt[k]) (void)dev_free(ctx->long_alt[k]);
     }
     for (int k = 0; k < vr_ctx::kRangeRing; k++) {
-        if (ctx->tiles_ring[k]) (void)hipFree(ctx->tiles_ring[k]);
+        if (ctx->tiles_ring[k]) (void)dev_free(ctx->tiles_ring[k]);
         if (ctx->ranges_done[k]) (void)hipEventDestroy(ctx->ranges_done[k]);
         if (ctx->ranges_free[k]) (void)hipEventDestroy(ctx->ranges_free[k]);
     }
@@ -667,20 +746,22 @@ int vr_destroy(vr_ctx *ctx)
     }
     if (ctx->frame_done) (void)hipEventDestroy(ctx->frame_done);
     if (ctx->tail_stream) (void)hipStreamDestroy(ctx->tail_stream);
-    if (ctx->lut) (void)hipFree(ctx->lut);
-    if (ctx->d_pts) (void)hipFree(ctx->d_pts);
-    if (ctx->counters) (void)hipFree(ctx->counters);
-    if (ctx->frame) (void)hipFree(ctx->frame);
-    if (ctx->partial) (void)hipFree(ctx->partial);
-    if (ctx->queue) (void)hipFree(ctx->queue);
-    if (ctx->long_queue) (void)hipFree(ctx->long_queue);
-    if (ctx->lut_info) (void)hipFree(ctx->lut_info);
-    if (ctx->occ) (void)hipFree(ctx->occ);
-    if (ctx->d_occ_count) (void)hipFree(ctx->d_occ_count);
-    if (ctx->tiles) (void)hipFree(ctx->tiles);
+    if (ctx->lut) (void)dev_free(ctx->lut);
+    if (ctx->d_pts) (void)dev_free(ctx->d_pts);
+    if (ctx->counters) (void)dev_free(ctx->counters);
+    if (ctx->frame) (void)dev_free(ctx->frame);
+    if (ctx->partial) (void)dev_free(ctx->partial);
+    if (ctx->queue) (void)dev_free(ctx->queue);
+    if (ctx->long_queue) (void)dev_free(ctx->long_queue);
+    if (ctx->lut_info) (void)dev_free(ctx->lut_info);
+    if (ctx->occ) (void)dev_free(ctx->occ);
+    if (ctx->d_occ_count) (void)dev_free(ctx->d_occ_count);
+    if (ctx->occ_ready) (void)hipEventDestroy(ctx->occ_ready);
+    if (ctx->probe_word) (void)hipHostFree(ctx->probe_word);
+    if (ctx->tiles) (void)dev_free(ctx->tiles);
     for (int k = 0; k < vr_ctx::kSets; k++) {
-        if (ctx->order_lists[k]) (void)hipFree(ctx->order_lists[k]);
-        if (ctx->tile_ticks[k]) (void)hipFree(ctx->tile_ticks[k]);
+        if (ctx->order_lists[k]) (void)dev_free(ctx->order_lists[k]);
+        if (ctx->tile_ticks[k]) (void)dev_free(ctx->tile_ticks[k]);
     }
     for (hipEvent_t e : ctx->ring_a)
         if (e) (void)hipEventDestroy(e);
@@ -724,7 +805,7 @@ int vr_set_pipeline(vr_ctx *ctx, int frames_in_flight)
         }
         VR_HIP(ctx, hipStreamCreateWithFlags(&ctx->prep_stream, hipStreamNonBlocking));
         for (int k = 0; k < vr_ctx::kSets - 1; k++) {
-            VR_HIP(ctx, hipMalloc(&ctx->counters_alt[k], sizeof(vr::Counters)));
+            VR_HIP(ctx, dev_alloc(&ctx->counters_alt[k], sizeof(vr::Counters)));
             VR_HIP(ctx, hipMemsetAsync(ctx->counters_alt[k], 0, sizeof(vr::Counters), ctx->stream));
         }
         // The finishing kernels are short chains of dependent steps and may be given their few waves first
@@ -771,12 +852,12 @@ int vr_upload_volume(vr_ctx *ctx, const void *voxels, int dtype, int nx, int ny,
     if (int rc = bind(ctx)) return rc;
     const size_t bytes = (size_t)nx * ny * nz * (size_t)dtype;
     void *d_raw = nullptr;
-    VR_HIP(ctx, hipMalloc(&d_raw, bytes));
+    VR_HIP(ctx, dev_alloc(&d_raw, bytes));
     hipError_t e = hipMemcpyAsync(d_raw, voxels, bytes, hipMemcpyHostToDevice, ctx->stream);
     int rc = VR_OK;
     if (e != hipSuccess) rc = fail(ctx, VR_ERR_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e));
     if (rc == VR_OK) rc = vr_upload_volume_device(ctx, d_raw, dtype, nx, ny, nz, max_value);
-    (void)hipFree(d_raw);
+    (void)dev_free(d_raw);
     return rc;
 }
 
@@ -821,12 +902,12 @@ int vr_load_volume_slices(vr_ctx *ctx, const char *directory)
     if (side < 1 || (size_t)side * side * slices != raw.size())
         return fail(ctx, VR_ERR_IO, "slice files are not equally sized squares");
     uint16_t *d_raw = nullptr;
-    VR_HIP(ctx, hipMalloc(&d_raw, raw.size() * 2));
+    VR_HIP(ctx, dev_alloc(&d_raw, raw.size() * 2));
     hipError_t e = hipMemcpyAsync(d_raw, raw.data(), raw.size() * 2, hipMemcpyHostToDevice, ctx->stream);
     int rc = VR_OK;
     if (e != hipSuccess) rc = fail(ctx, VR_ERR_HIP, std::string("hipMemcpyAsync: ") + hipGetErrorString(e));
     if (rc == VR_OK) rc = ingest_device<uint16_t>(ctx, d_raw, side, side, slices, 0.0f, true);
-    (void)hipFree(d_raw);
+    (void)dev_free(d_raw);
     return rc;
 }
 
@@ -850,7 +931,7 @@ int vr_read_volume_normalized(vr_ctx *ctx, float *out)
     if (int rc = bind(ctx)) return rc;
     const size_t count = (size_t)ctx->nx * ctx->ny * ctx->nz;
     float *d = nullptr;
-    VR_HIP(ctx, hipMalloc(&d, count * sizeof(float)));
+    VR_HIP(ctx, dev_alloc(&d, count * sizeof(float)));
     const int blocks = (int)std::min<size_t>((count + 255) / 256, 256 * 16);
     if (ctx->dtype == VR_DTYPE_U8)
         hipLaunchKernelGGL((vr::k_read_normalized<uint8_t>), dim3(blocks), dim3(256), 0, ctx->stream, view_of(ctx), d);
@@ -858,7 +939,7 @@ int vr_read_volume_normalized(vr_ctx *ctx, float *out)
         hipLaunchKernelGGL((vr::k_read_normalized<uint16_t>), dim3(blocks), dim3(256), 0, ctx->stream, view_of(ctx), d);
     hipError_t e = hipMemcpyAsync(out, d, count * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d);
+    (void)dev_free(d);
     if (e != hipSuccess) return fail(ctx, VR_ERR_HIP, hipGetErrorString(e));
     return VR_OK;
 }
@@ -871,7 +952,7 @@ int vr_histogram(vr_ctx *ctx, float out[100])
     if (int rc = bind(ctx)) return rc;
     const size_t bins = 65536;
     unsigned long long *d_hist = nullptr;
-    VR_HIP(ctx, hipMalloc(&d_hist, bins * sizeof(unsigned long long)));
+    VR_HIP(ctx, dev_alloc(&d_hist, bins * sizeof(unsigned long long)));
     hipError_t e = hipMemsetAsync(d_hist, 0, bins * sizeof(unsigned long long), ctx->stream);
     const unsigned blocks = (unsigned)std::min<size_t>((ctx->brick_count * 64 + 255) / 256, 256 * 64);
     if (ctx->dtype == VR_DTYPE_U8)
@@ -882,7 +963,7 @@ int vr_histogram(vr_ctx *ctx, float out[100])
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(counts.data(), d_hist, bins * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d_hist);
+    (void)dev_free(d_hist);
     if (e != hipSuccess) return fail(ctx, VR_ERR_HIP, hipGetErrorString(e));
 
     // main.cpp:166-181 on the sorted normalised values, which are runs of float(v)/float(max), v ascending:
@@ -931,25 +1012,41 @@ int vr_set_transfer_function(vr_ctx *ctx, const vr_ctrl_pt *const points[4], con
             return fail(ctx, VR_ERR_ARG, "the last control point needs x > 0 (x is divided by it, main.cpp:653)");
         offs[c + 1] = (int)packed.size();
     }
-    if (packed.size() > ctx->d_pts_cap) {
-        if (ctx->d_pts) (void)hipFree(ctx->d_pts);
-        ctx->d_pts = nullptr;
-        ctx->d_pts_cap = 0;
-        const size_t cap = std::max<size_t>(64, packed.size() * 2);
-        VR_HIP(ctx, hipMalloc(&ctx->d_pts, cap * sizeof(vr::CtrlPt)));
-        ctx->d_pts_cap = cap;
-    }
+    const bool same = packed.size() == ctx->last_pts.size() && std::memcmp(offs, ctx->last_offs, sizeof offs) == 0 &&
+                      (packed.empty() || std::memcmp(packed.data(), ctx->last_pts.data(), packed.size() * sizeof(vr::CtrlPt)) == 0);
+    if (same && (!reset_state || ctx->table_from_zero)) return VR_OK;   // every bit of the table stays as it is
+    ctx->table_from_zero = reset_state != 0;
+    ctx->last_pts = packed;
+    std::memcpy(ctx->last_offs, offs, sizeof offs);
     ctx->occupancy_dirty = true;
+    ctx->table_epoch++;
+    ctx->fast_fallback = false;
     drain(ctx);   // frames still being finished read the table
     if (reset_state) VR_HIP(ctx, hipMemsetAsync(ctx->lut, 0, 1024 * sizeof(float), ctx->stream));
-    if (!packed.empty()) {
-        // synchronous on purpose: `packed` lives on this stack frame
-        VR_HIP(ctx, hipMemcpyAsync(ctx->d_pts, packed.data(), packed.size() * sizeof(vr::CtrlPt), hipMemcpyHostToDevice, ctx->stream));
-        VR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        hipLaunchKernelGGL(vr::k_lut_update, dim3(1), dim3(256), 0, ctx->stream, ctx->lut, ctx->d_pts, offs[0], offs[1], offs[2],
-                           offs[3], offs[4], ctx->counters);
+    if (packed.empty()) return VR_OK;
+    if (packed.size() <= (size_t)vr::kLutArgPoints) {
+        // the points travel with the launch: no staging buffer, no copy, nothing to wait for
+        vr::LutPointsArg arg;
+        std::memcpy(arg.p, packed.data(), packed.size() * sizeof(vr::CtrlPt));
+        hipLaunchKernelGGL((vr::k_lut_update<true>), dim3(1), dim3(256), 0, ctx->stream, ctx->lut, (const vr::CtrlPt *)nullptr, arg, offs[0],
+                           offs[1], offs[2], offs[3], offs[4], ctx->counters);
         VR_HIP(ctx, hipGetLastError());
+        return VR_OK;
     }
+    if (packed.size() > ctx->d_pts_cap) {
+        if (ctx->d_pts) (void)dev_free(ctx->d_pts);
+        ctx->d_pts = nullptr;
+        ctx->d_pts_cap = 0;
+        const size_t cap = std::max<size_t>(1024, packed.size() * 2);
+        VR_HIP(ctx, dev_alloc(&ctx->d_pts, cap * sizeof(vr::CtrlPt)));
+        ctx->d_pts_cap = cap;
+    }
+    // synchronous on purpose: `packed` lives on this stack frame
+    VR_HIP(ctx, hipMemcpyAsync(ctx->d_pts, packed.data(), packed.size() * sizeof(vr::CtrlPt), hipMemcpyHostToDevice, ctx->stream));
+    VR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    hipLaunchKernelGGL((vr::k_lut_update<false>), dim3(1), dim3(256), 0, ctx->stream, ctx->lut, ctx->d_pts, vr::LutPointsArg{}, offs[0], offs[1],
+                       offs[2], offs[3], offs[4], ctx->counters);
+    VR_HIP(ctx, hipGetLastError());
     return VR_OK;
 }
 
@@ -1014,13 +1111,15 @@ int vr_set_sampling(vr_ctx *ctx, int samples_per_ray, const float tf_border_rgba
     if (!ctx) return VR_ERR_ARG;
     if (samples_per_ray < 0 || samples_per_ray > (1 << 20)) return fail(ctx, VR_ERR_ARG, "samples_per_ray out of range");
     if (ctx->samples != samples_per_ray) {
-        ctx->fast_probe = true;
+        ctx->table_epoch++;
         ctx->fast_fallback = false;
     }
     ctx->samples = samples_per_ray;
     if (tf_border_rgba && std::memcmp(ctx->border, tf_border_rgba, sizeof ctx->border) != 0) {
         std::memcpy(ctx->border, tf_border_rgba, sizeof ctx->border);
         ctx->occupancy_dirty = true;
+        ctx->table_epoch++;
+        ctx->fast_fallback = false;
     }
     return VR_OK;
 }
@@ -1044,6 +1143,8 @@ int vr_set_shading(vr_ctx *ctx, int enabled, const float scene[4])
         ctx->shading = on;
         std::memcpy(ctx->scene, next, sizeof next);
         ctx->occupancy_dirty = true;   // the colour range the early decisions rely on includes the illumination
+        ctx->table_epoch++;
+        ctx->fast_fallback = false;
     }
     return VR_OK;
 }
@@ -1088,10 +1189,10 @@ static int render_impl(vr_ctx *ctx, int width, int height, int x0, int y0, int x
     uint32_t *d_out = reinterpret_cast<uint32_t *>(out);
     if (!out_is_device) {
         if (pixels > ctx->frame_cap) {
-            if (ctx->frame) (void)hipFree(ctx->frame);
+            if (ctx->frame) (void)dev_free(ctx->frame);
             ctx->frame = nullptr;
             ctx->frame_cap = 0;
-            VR_HIP(ctx, hipMalloc(&ctx->frame, pixels * 4));
+            VR_HIP(ctx, dev_alloc(&ctx->frame, pixels * 4));
             ctx->frame_cap = pixels;
         }
         d_out = ctx->frame;
@@ -1099,7 +1200,12 @@ static int render_impl(vr_ctx *ctx, int width, int height, int x0, int y0, int x
     const bool want_stats = stats != nullptr;
     if (ctx->mode != VR_MODE_REFERENCE_ORDER && ctx->occupancy_dirty) {
         drain(ctx);
-        if (int rc = refresh_occupancy(ctx)) return rc;    // also re-arms the fast mode's probe
+        if (int rc = refresh_occupancy(ctx)) return rc;
+    }
+    poll_probe(ctx);
+    if (ctx->mode == VR_MODE_FAST && ctx->fast_fallback && ++ctx->fallback_frames >= vr_ctx::kFallbackRetry) {
+        ctx->fast_fallback = false;   // one fast frame to look again; its report decides what follows
+        ctx->fallback_frames = 0;
     }
     const bool fast = ctx->mode == VR_MODE_FAST && !ctx->fast_fallback;
     unsigned char *sp = nullptr;
@@ -1113,23 +1219,23 @@ static int render_impl(vr_ctx *ctx, int width, int height, int x0, int y0, int x
         if (!sp) return fail(ctx, VR_ERR_STATE, "no static scratch on this device");
     }
     if (!use_static && fast && pixels > ctx->queue_cap) {
-        if (ctx->queue) (void)hipFree(ctx->queue);
-        if (ctx->long_queue) (void)hipFree(ctx->long_queue);
+        if (ctx->queue) (void)dev_free(ctx->queue);
+        if (ctx->long_queue) (void)dev_free(ctx->long_queue);
         ctx->queue = nullptr;
         ctx->long_queue = nullptr;
         ctx->queue_cap = 0;
-        VR_HIP(ctx, hipMalloc(&ctx->queue, pixels * sizeof(vr::ReplayRay)));
-        VR_HIP(ctx, hipMalloc(&ctx->long_queue, pixels * sizeof(vr::LongRay)));
+        VR_HIP(ctx, dev_alloc(&ctx->queue, pixels * sizeof(vr::ReplayRay)));
+        VR_HIP(ctx, dev_alloc(&ctx->long_queue, pixels * sizeof(vr::LongRay)));
         ctx->queue_cap = pixels;
     }
     if (fast && !use_static) {
         const int tile_px = 1 << vr::kRangeShift;
         const size_t tile_count = (size_t)((width + tile_px - 1) / tile_px) * (size_t)((height + tile_px - 1) / tile_px);
         if (tile_count > ctx->tiles_cap) {
-            if (ctx->tiles) (void)hipFree(ctx->tiles);
+            if (ctx->tiles) (void)dev_free(ctx->tiles);
             ctx->tiles = nullptr;
             ctx->tiles_cap = 0;
-            VR_HIP(ctx, hipMalloc(&ctx->tiles, (tile_count + 1) * sizeof(uint2)));
+            VR_HIP(ctx, dev_alloc(&ctx->tiles, (tile_count + 1) * sizeof(uint2)));
             ctx->tiles_cap = tile_count;
         }
     }
@@ -1153,23 +1259,23 @@ static int render_impl(vr_ctx *ctx, int width, int height, int x0, int y0, int x
             drain(ctx);
             VR_HIP(ctx, hipStreamSynchronize(ctx->stream));
             for (int k = 0; k < vr_ctx::kSets - 1; k++) {
-                if (ctx->queue_alt[k]) (void)hipFree(ctx->queue_alt[k]);
-                if (ctx->long_alt[k]) (void)hipFree(ctx->long_alt[k]);
+                if (ctx->queue_alt[k]) (void)dev_free(ctx->queue_alt[k]);
+                if (ctx->long_alt[k]) (void)dev_free(ctx->long_alt[k]);
                 ctx->queue_alt[k] = nullptr;
                 ctx->long_alt[k] = nullptr;
             }
             ctx->alt_queue_cap = 0;
             for (int k = 0; k < vr_ctx::kRangeRing; k++) {
-                if (ctx->tiles_ring[k]) (void)hipFree(ctx->tiles_ring[k]);
+                if (ctx->tiles_ring[k]) (void)dev_free(ctx->tiles_ring[k]);
                 ctx->tiles_ring[k] = nullptr;
                 ctx->ranges_busy[k] = false;
             }
             ctx->tiles_ring_cap = 0;
             for (int k = 0; k < vr_ctx::kSets - 1; k++) {
-                VR_HIP(ctx, hipMalloc(&ctx->queue_alt[k], pixels * sizeof(vr::ReplayRay)));
-                VR_HIP(ctx, hipMalloc(&ctx->long_alt[k], pixels * sizeof(vr::LongRay)));
+                VR_HIP(ctx, dev_alloc(&ctx->queue_alt[k], pixels * sizeof(vr::ReplayRay)));
+                VR_HIP(ctx, dev_alloc(&ctx->long_alt[k], pixels * sizeof(vr::LongRay)));
             }
-            for (int k = 0; k < vr_ctx::kRangeRing; k++) VR_HIP(ctx, hipMalloc(&ctx->tiles_ring[k], (tile_count + 1) * sizeof(uint2)));
+            for (int k = 0; k < vr_ctx::kRangeRing; k++) VR_HIP(ctx, dev_alloc(&ctx->tiles_ring[k], (tile_count + 1) * sizeof(uint2)));
             ctx->alt_queue_cap = pixels;
             ctx->tiles_ring_cap = tile_count;
         }
@@ -1204,8 +1310,15 @@ static int render_impl(vr_ctx *ctx, int width, int height, int x0, int y0, int x
     if (!(piped && ctx->counters_clean[set])) VR_HIP(ctx, hipMemsetAsync(fb.counters, 0, offsetof(vr::Counters, lut_error), main_s));
     for (int k = 0; k < vr_ctx::kSets; k++)
         if (k == set || !piped) ctx->counters_clean[k] = false;   // frames outside the pipeline use set 0's and tell nobody
-    fb.clear_after = piped && !ctx->fast_probe;    // the probe frame's counters are read after the frame
+    fb.clear_after = piped;
     if (fb.clear_after) ctx->counters_clean[set] = true;
+    if (fast) {
+        fb.seq = ++ctx->frame_seq;
+        if (fb.seq == 0u) fb.seq = ++ctx->frame_seq;   // 0 means "no report yet"
+        // a rectangle cut out of the frame says little about the table (one on the outline is all replay)
+        ctx->probe_meta[fb.seq & 7u] = vr_ctx::ProbeMeta{fb.seq, ctx->table_epoch, pixels,
+                                                         pixels >= 4096 && x0 == 0 && y0 == 0 && x1 == width && y1 == height};
+    }
     if (want_stats)
         VR_HIP(ctx, hipMemsetAsync(ctx->touched, 0, ((ctx->brick_count + 31) / 32) * sizeof(uint32_t), main_s));
 
@@ -1225,16 +1338,6 @@ static int render_impl(vr_ctx *ctx, int width, int height, int x0, int y0, int x
         ctx->last_set = -1;
     }
     if (!piped) VR_HIP(ctx, hipEventRecord(ctx->ev1, main_s));
-
-    if (fast && ctx->fast_probe && pixels >= 4096) {
-        // the probe frame: how many of its pixels went through the replay?
-        vr::Counters c;
-        if (piped) VR_HIP(ctx, hipStreamSynchronize(ctx->tail_stream));
-        VR_HIP(ctx, hipMemcpyAsync(&c, fb.counters, sizeof c, hipMemcpyDeviceToHost, main_s));
-        VR_HIP(ctx, hipStreamSynchronize(main_s));
-        ctx->fast_probe = false;
-        ctx->fast_fallback = (size_t)c.replay_count * 10u > pixels;
-    }
 
     if (!out_is_device) {
         VR_HIP(ctx, hipMemcpyAsync(out, d_out, pixels * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1292,9 +1395,11 @@ int vr_render_static(vr_ctx *ctx, int width, int height, uint8_t *d_out)
 {
     if (!ctx) return VR_ERR_ARG;
     const int mode = ctx->mode;
+    const unsigned long long refused = g_forbidden_calls;
     ctx->mode = VR_MODE_FAST;
     const int rc = render_impl(ctx, width, height, 0, 0, width, height, 0, 1, d_out, 1, nullptr, true);
     ctx->mode = mode;
+    if (rc == VR_OK && g_forbidden_calls != refused) return fail(ctx, VR_ERR_STATE, "vr_render_static tried to allocate or free device memory");
     return rc;
 }
 
@@ -1337,7 +1442,7 @@ int vr_tune(vr_ctx *ctx, int width, int height, int part, int parts, int *chosen
         if (part != 0 || parts != 1) return fail(ctx, VR_ERR_ARG, "a box of a split volume renders whole partial images");
         if (ctx->shading) return fail(ctx, VR_ERR_STATE, "shading is on: the partial march has no lighting");
         float *d_partial = nullptr;
-        VR_HIP(ctx, hipMalloc(&d_partial, (size_t)width * (size_t)height * vr::kPartial * sizeof(float)));
+        VR_HIP(ctx, dev_alloc(&d_partial, (size_t)width * (size_t)height * vr::kPartial * sizeof(float)));
         const int before = ctx->partial_budget;
         int best = before, rc = VR_OK;
         double best_s = 1.0e300;
@@ -1359,7 +1464,7 @@ int vr_tune(vr_ctx *ctx, int width, int height, int part, int parts, int *chosen
         }
         ctx->partial_budget = rc == VR_OK ? best : before;
         (void)hipStreamSynchronize(ctx->stream);
-        (void)hipFree(d_partial);
+        (void)dev_free(d_partial);
         if (rc == VR_OK && chosen_budget) *chosen_budget = best;
         return rc;
     }
@@ -1367,7 +1472,7 @@ int vr_tune(vr_ctx *ctx, int width, int height, int part, int parts, int *chosen
     // one allocation, three frames in turn (frames in flight must not share their output)
     const size_t frame_bytes = (pixels * 4 + 255) & ~(size_t)255;
     uint8_t *scratch = nullptr;
-    VR_HIP(ctx, hipMalloc(&scratch, 3 * frame_bytes));
+    VR_HIP(ctx, dev_alloc(&scratch, 3 * frame_bytes));
     const int mode = ctx->mode, before = ctx->lane_budget;
     ctx->mode = VR_MODE_FAST;
     // How long a lane stays with its ray before it hands it to a wave of its own: the best value
@@ -1399,7 +1504,7 @@ int vr_tune(vr_ctx *ctx, int width, int height, int part, int parts, int *chosen
     ctx->mode = mode;
     drain(ctx);
     (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(scratch);
+    (void)dev_free(scratch);
     if (rc == VR_OK && chosen_budget) *chosen_budget = best;
     return rc;
 }
@@ -1567,22 +1672,22 @@ int vr_render_partial(vr_ctx *ctx, int width, int height, float *out, int out_is
     drain(ctx);
     if (!out_is_device) {
         if (pixels > ctx->partial_cap) {
-            if (ctx->partial) (void)hipFree(ctx->partial);
+            if (ctx->partial) (void)dev_free(ctx->partial);
             ctx->partial = nullptr;
             ctx->partial_cap = 0;
-            VR_HIP(ctx, hipMalloc(&ctx->partial, pixels * vr::kPartial * sizeof(float)));
+            VR_HIP(ctx, dev_alloc(&ctx->partial, pixels * vr::kPartial * sizeof(float)));
             ctx->partial_cap = pixels;
         }
         d_out = ctx->partial;
     }
     if (pixels > ctx->queue_cap) {
-        if (ctx->queue) (void)hipFree(ctx->queue);
-        if (ctx->long_queue) (void)hipFree(ctx->long_queue);
+        if (ctx->queue) (void)dev_free(ctx->queue);
+        if (ctx->long_queue) (void)dev_free(ctx->long_queue);
         ctx->queue = nullptr;
         ctx->long_queue = nullptr;
         ctx->queue_cap = 0;
-        VR_HIP(ctx, hipMalloc(&ctx->queue, pixels * sizeof(vr::ReplayRay)));
-        VR_HIP(ctx, hipMalloc(&ctx->long_queue, pixels * sizeof(vr::LongRay)));
+        VR_HIP(ctx, dev_alloc(&ctx->queue, pixels * sizeof(vr::ReplayRay)));
+        VR_HIP(ctx, dev_alloc(&ctx->long_queue, pixels * sizeof(vr::LongRay)));
         ctx->queue_cap = pixels;
     }
     if (int rc = refresh_occupancy(ctx)) return rc;
@@ -1598,17 +1703,17 @@ int vr_render_partial(vr_ctx *ctx, int width, int height, float *out, int out_is
     const int tiles_x = (width + tile_px - 1) / tile_px, tiles_y = (height + tile_px - 1) / tile_px;
     const size_t tile_count = (size_t)tiles_x * tiles_y;
     if (tile_count > ctx->tiles_cap) {
-        if (ctx->tiles) (void)hipFree(ctx->tiles);
+        if (ctx->tiles) (void)dev_free(ctx->tiles);
         ctx->tiles = nullptr;
         ctx->tiles_cap = 0;
-        VR_HIP(ctx, hipMalloc(&ctx->tiles, (tile_count + 1) * sizeof(uint2)));
+        VR_HIP(ctx, dev_alloc(&ctx->tiles, (tile_count + 1) * sizeof(uint2)));
         ctx->tiles_cap = tile_count;
     }
     const uint2 *range = nullptr;
-    if (ctx->tile_clip && ctx->occ_count > 0) {
+    if (ctx->tile_clip) {
         VR_HIP(ctx, hipMemsetAsync(ctx->tiles, 0, (tile_count + 1) * sizeof(uint2), ctx->stream));
-        hipLaunchKernelGGL(vr::k_splat_bricks, dim3((ctx->occ_count + 255) / 256), dim3(256), 0, ctx->stream, vol, fp, ctx->occ_list,
-                           ctx->occ_count, ctx->tiles, tiles_x, tiles_y, ctx->counters);
+        hipLaunchKernelGGL(vr::k_splat_bricks, dim3(splat_blocks(ctx)), dim3(256), 0, ctx->stream, vol, fp, ctx->occ_list,
+                           ctx->d_occ_count, ctx->tiles, tiles_x, tiles_y, ctx->counters);
         range = ctx->tiles;
     }
     if (ctx->dtype == VR_DTYPE_U8) {

@@ -9,6 +9,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 namespace vr {
@@ -407,11 +408,6 @@ __device__ __forceinline__ void pixel_of_index(const FrameParams &fp, uint32_t o
     py = fp.y0 + (int)(((row >> 4) * (uint32_t)fp.parts + (uint32_t)fp.part) * 16u + (row & 15u));
 }
 
-// ---- transfer function table ---------------------------------------------------------------
-// updateTransferFunction, Applications/VolumeRendering/Source/main.cpp:643-686, one wave per
-// channel.  Segments are applied in order (a later segment overwrites the pixel it shares with
-// the previous one, main.cpp:660-681); inside a segment the written pixels are distinct, so the
-// lanes of a wave can take one k each.  Table entries no segment covers keep their old value.
 // Sort-first assembly: `src` holds the parts' dense band buffers one after the other, `stride` pixels
 // apart; row y of the frame is row (y / 16 / parts) * 16 + y % 16 of part (y / 16) % parts.
 __global__ __launch_bounds__(256) void k_assemble_bands(const uint32_t *__restrict__ src, size_t stride, int parts, int width,
@@ -425,25 +421,40 @@ __global__ __launch_bounds__(256) void k_assemble_bands(const uint32_t *__restri
     dst[i] = src[(size_t)(band % parts) * stride + row * (size_t)width + (size_t)x];
 }
 
+// ---- transfer function table ---------------------------------------------------------------
+// updateTransferFunction, Applications/VolumeRendering/Source/main.cpp:643-686, one wave per
+// channel.  Segments are applied in order (a later segment overwrites the pixel it shares with
+// the previous one, main.cpp:660-681); inside a segment the written pixels are distinct, so the
+// lanes of a wave can take one k each.  Table entries no segment covers keep their old value.
 struct CtrlPt {
     float x, intensity;
 };
 
-__global__ __launch_bounds__(256) void k_lut_update(float *__restrict__ lut, const CtrlPt *__restrict__ pts,
+// Control graphs small enough travel as a kernel argument (no staging buffer, no copy, nothing for the host
+// to wait for): the editor's graphs hold a handful of points each.
+constexpr int kLutArgPoints = 256;
+struct LutPointsArg {
+    CtrlPt p[kLutArgPoints];
+};
+
+// ARG: the points are read from `arg`, else from `pts` in device memory.
+template <bool ARG>
+__global__ __launch_bounds__(256) void k_lut_update(float *__restrict__ lut, const CtrlPt *__restrict__ pts, LutPointsArg arg,
                                                    int off0, int off1, int off2, int off3, int off4, Counters *ctr)
 {
     __shared__ float s_chan[4][256];
-    const int lane = threadIdx.x & 63, ch = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, ch = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int offs[5] = {off0, off1, off2, off3, off4};
     const int begin = offs[ch], cnt = offs[ch + 1] - offs[ch];
     for (int i = lane; i < 256; i += 64) s_chan[ch][i] = lut[i * 4 + ch];
     if (cnt >= 1) {
-        const CtrlPt *g = pts + begin;
-        const float x_last = g[cnt - 1].x;
+        auto point = [&](int k) -> CtrlPt { return ARG ? arg.p[begin + k] : pts[begin + k]; };
+        const float x_last = point(cnt - 1).x;
         for (int j = 1; j < cnt; j++) {
-            const float xa = (g[j - 1].x / x_last) * 255.0f;
-            const float xb = (g[j].x / x_last) * 255.0f;
-            const float dir = g[j].intensity - g[j - 1].intensity;
+            const CtrlPt ga = point(j - 1), gb = point(j);
+            const float xa = (ga.x / x_last) * 255.0f;
+            const float xb = (gb.x / x_last) * 255.0f;
+            const float dir = gb.intensity - ga.intensity;
             const float total = xb - xa + 1.0f;
             uint32_t count = 0;
             if (total >= 1.0f) count = total >= 4294967296.0f ? 0xFFFFFFFFu : (uint32_t)total;
@@ -454,7 +465,7 @@ __global__ __launch_bounds__(256) void k_lut_update(float *__restrict__ lut, con
             for (uint32_t k0 = 0; k0 < count; k0 += 64) {
                 const uint32_t k = k0 + lane;
                 if (k < count) {
-                    const float val = g[j - 1].intensity + dir * ((float)k / (total - 1.0f));
+                    const float val = ga.intensity + dir * ((float)k / (total - 1.0f));
                     const float pixel = xa + (float)k;
                     if (pixel >= 0.0f && pixel < 256.0f) s_chan[ch][(int)pixel] = val;
                     else atomicOr(&ctr->lut_error, 1u);

@@ -30,16 +30,25 @@ struct LutInfo {
     float cmin[3], cmax[3];  // range of the colour channels over table and border
     float kappa[3];          // per channel: bound of the rounding error one blend step adds
     uint32_t fast_ok;        // all alphas in [0,1] and all colours finite
-    uint32_t pad_;
+    // What the last k_lut_derive found when it compared the table with the one the occupancy tables were
+    // built for.  The occupancy of a brick or block depends on the table only through the set of bad entries,
+    // so the kernels that rebuild the occupancy tables are always enqueued after a change of table and return
+    // at once when `changed` is 0: the host never has to ask.
+    uint32_t changed;        // the set of bad entries differs, or the volume is new: rebuild
+    int chg_first, chg_last; // entries of the LDS table whose badness changed lie in [chg_first, chg_last]
 };
 
 constexpr float kUlpHalf = 5.9604644775390625e-08f;  // 2^-24
 
 // One block.  Derives LutInfo from the table and the border colour.
 // shade_hi: largest value the local illumination adds to a tap's colour (0 when it is off).
-__global__ __launch_bounds__(256) void k_lut_derive(const float4 *__restrict__ lut, float4 border, float shade_hi, LutInfo *info)
+// force: the occupancy tables have to be rebuilt whatever the table says (new volume; `info` may be
+// uninitialised then).  When a rebuild is due the bounding box of the occupied bricks and the length of the
+// list of surface bricks are reset here, in front of the kernels that rebuild them.
+__global__ __launch_bounds__(256) void k_lut_derive(const float4 *__restrict__ lut, float4 border, float shade_hi, int force,
+                                                   LutInfo *info, int *occ, uint32_t *occ_count)
 {
-    __shared__ uint32_t s_bad[kLutLds];
+    __shared__ uint32_t s_bad[kLutLds], s_old[kLutLds];
     __shared__ float s_min[3][256], s_max[3][256];
     __shared__ uint32_t s_ok[256];
     const int tid = threadIdx.x;
@@ -50,6 +59,7 @@ __global__ __launch_bounds__(256) void k_lut_derive(const float4 *__restrict__ l
         if (i >= 2 && i < 258) v = lut[i - 2];
         const bool finite = isfinite(v.x) && isfinite(v.y) && isfinite(v.z);
         s_bad[i] = (v.w != 0.0f || !finite) ? 1u : 0u;
+        s_old[i] = force ? 2u : info->bad_prefix[i + 1] - info->bad_prefix[i];   // 2: differs from any new value
         if (!finite || !(v.w >= 0.0f && v.w <= 1.0f)) ok = 0;
         const float ch[3] = {v.x, v.y, v.z};
         for (int c = 0; c < 3; c++) {
@@ -65,11 +75,24 @@ __global__ __launch_bounds__(256) void k_lut_derive(const float4 *__restrict__ l
     __syncthreads();
     if (tid == 0) {
         uint32_t run = 0;
+        int first = kLutLds, last = -1;
         for (int i = 0; i < kLutLds; i++) {
             info->bad_prefix[i] = run;
             run += s_bad[i];
+            if (s_bad[i] != s_old[i]) {
+                first = i < first ? i : first;
+                last = i;
+            }
         }
         info->bad_prefix[kLutLds] = run;
+        info->changed = last >= 0 ? 1u : 0u;
+        info->chg_first = first;
+        info->chg_last = last;
+        if (last >= 0) {
+            occ[0] = occ[1] = occ[2] = 0x7fffffff;   // empty box: lo > hi
+            occ[3] = occ[4] = occ[5] = -1;
+            *occ_count = 0u;
+        }
         uint32_t all_ok = 1;
         float lo[3] = {s_min[0][0], s_min[1][0], s_min[2][0]}, hi[3] = {s_max[0][0], s_max[1][0], s_max[2][0]};
         for (int k = 0; k < 256; k++) {
@@ -91,7 +114,6 @@ __global__ __launch_bounds__(256) void k_lut_derive(const float4 *__restrict__ l
             info->kappa[c] = 3.25f * kUlpHalf * (mag + slack);
         }
         info->fast_ok = all_ok;
-        info->pad_ = 0;
     }
 }
 
@@ -122,6 +144,7 @@ __global__ __launch_bounds__(256) void k_classify_bricks(const uint32_t *__restr
                                                         float inv_hi, float inv_lo, const LutInfo *__restrict__ info,
                                                         uint32_t *__restrict__ empty0)
 {
+    if (!info->changed) return;
     const uint32_t b = blockIdx.x * 256u + threadIdx.x;
     bool empty = false;
     if (b < brick_count) {
@@ -135,9 +158,10 @@ __global__ __launch_bounds__(256) void k_classify_bricks(const uint32_t *__restr
 }
 
 // Level l+1 from level l: a cube is empty when its (up to) 4^3 children inside the grid are.
-__global__ __launch_bounds__(256) void k_classify_up(const uint32_t *__restrict__ child, int cnx, int cny, int cnz, int px,
-                                                    int py, int pz, uint32_t *__restrict__ parent)
+__global__ __launch_bounds__(256) void k_classify_up(const LutInfo *__restrict__ info, const uint32_t *__restrict__ child, int cnx,
+                                                    int cny, int cnz, int px, int py, int pz, uint32_t *__restrict__ parent)
 {
+    if (!info->changed) return;
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     const uint32_t count = (uint32_t)(px * py * pz);
     bool empty = false;
@@ -163,16 +187,28 @@ __global__ __launch_bounds__(256) void k_classify_up(const uint32_t *__restrict_
 // corner lies in block (bx, by, bz) of the brick filters the voxels [2b, 2b+2]^3 (local, apron
 // included); the block is empty when the transfer function is exactly transparent over their range.
 // One wave per brick, one lane per block.  Empty bricks get all ones without touching their voxels.
+// After a change of table only the bricks whose value range reads an entry whose badness changed are
+// looked at again (the range of a block lies inside its brick's): dragging a control point re-reads the
+// voxels of the bricks around the threshold it moves, not the volume.
 template <typename T>
 __global__ __launch_bounds__(256) void k_classify_micro(const T *__restrict__ bricks, const uint32_t *__restrict__ empty0,
-                                                       uint32_t brick_count, float inv_hi, float inv_lo,
-                                                       const LutInfo *__restrict__ info,
+                                                       const uint32_t *__restrict__ cells, uint32_t brick_count, float inv_hi,
+                                                       float inv_lo, const LutInfo *__restrict__ info,
                                                        unsigned long long *__restrict__ micro)
 {
+    if (!info->changed) return;
+    const int chg_first = info->chg_first, chg_last = info->chg_last;
     const int lane = threadIdx.x & 63;
     const uint32_t waves = gridDim.x * 4u;
     const int bx = (lane & 3) * 2, by = ((lane >> 2) & 3) * 2, bz = (lane >> 4) * 2;
     for (uint32_t brick = blockIdx.x * 4u + (threadIdx.x >> 6); brick < brick_count; brick += waves) {
+        {
+            const uint32_t mm = cells[brick];
+            const float lo = (float)(mm & 0xffffu), hi = (float)(mm >> 16);
+            int first, last;
+            tf_entry_range(__builtin_fmaf(lo, inv_hi, lo * inv_lo), __builtin_fmaf(hi, inv_hi, hi * inv_lo), first, last);
+            if (last < chg_first || first > chg_last) continue;   // nothing this brick reads has changed: its word stands
+        }
         if ((empty0[brick >> 5] >> (brick & 31)) & 1u) {
             if (lane == 0) micro[brick] = ~0ull;
             continue;
@@ -303,8 +339,10 @@ __device__ __forceinline__ RayModel ray_model(const Ray &r, const VolumeView &v,
 }
 
 // Bounding box (brick coordinates, inclusive) of the occupied bricks; lo > hi when there is none.
-__global__ __launch_bounds__(256) void k_occupied_bounds(const uint32_t *__restrict__ empty0, int nx, int ny, int nz, int *occ)
+__global__ __launch_bounds__(256) void k_occupied_bounds(const LutInfo *__restrict__ info, const uint32_t *__restrict__ empty0, int nx,
+                                                        int ny, int nz, int *occ)
 {
+    if (!info->changed) return;
     __shared__ int s_lo[3][4], s_hi[3][4];
     const uint32_t bricks = (uint32_t)(nx * ny * nz);
     int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
@@ -366,9 +404,10 @@ constexpr int kRangeShift = VR_RANGE_SHIFT;
 // can be the first or last occupied brick of a ray, whatever the camera.  One wave looks at one cube of
 // 4^3 bricks and appends its finds in one piece, so bricks that are neighbours in space are neighbours
 // in the list (k_splat_bricks merges the ranges of a block's bricks per tile before it goes to memory).
-__global__ __launch_bounds__(256) void k_list_occupied(const uint32_t *__restrict__ empty0, int nbx, int nby, int nbz,
-                                                      uint32_t *__restrict__ list, uint32_t *count)
+__global__ __launch_bounds__(256) void k_list_occupied(const LutInfo *__restrict__ info, const uint32_t *__restrict__ empty0, int nbx,
+                                                      int nby, int nbz, uint32_t *__restrict__ list, uint32_t *count)
 {
+    if (!info->changed) return;
     const int lane = threadIdx.x & 63;
     const int gx_n = (nbx + 3) >> 2, gy_n = (nby + 3) >> 2, gz_n = (nbz + 3) >> 2;
     const uint32_t group = blockIdx.x * 4u + (threadIdx.x >> 6);
@@ -538,24 +577,31 @@ __device__ __forceinline__ void splat_one(const VolumeView &vol, const FramePara
 // Bricks next to each other in the list project onto the same few tiles, so a block first merges its
 // bricks' ranges per tile in LDS (a small open-addressing table keyed by the tile) and then raises
 // each tile of the table once in global memory: far fewer global atomics, which are the cost here.
+// The list's length is read from device memory (the kernel that rebuilds the list after a change of table
+// leaves it there; the host never learns it): the grid is sized for the longest list a volume can have and a
+// block takes every gridDim.x-th run of 256 entries, flushing its table after each.
 __global__ __launch_bounds__(256) void k_splat_bricks(VolumeView vol, FrameParams fp, const uint32_t *__restrict__ list,
-                                                     uint32_t count, uint2 *__restrict__ tiles, int tiles_x, int tiles_y,
-                                                     Counters *ctr)
+                                                     const uint32_t *__restrict__ count_ptr, uint2 *__restrict__ tiles, int tiles_x,
+                                                     int tiles_y, Counters *ctr)
 {
     static_assert(kSplatSlots == 1024, "the hash keeps the top 10 bits");
     __shared__ uint32_t s_tile[kSplatSlots], s_near[kSplatSlots], s_far[kSplatSlots];
-    for (uint32_t k = threadIdx.x; k < kSplatSlots; k += 256u) {
-        s_tile[k] = kNoTile;
-        s_near[k] = 0u;
-        s_far[k] = 0u;
-    }
-    __syncthreads();
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < count) splat_one(vol, fp, list[i], tiles, tiles_x, tiles_y, ctr, s_tile, s_near, s_far);
-    __syncthreads();
-    for (uint32_t k = threadIdx.x; k < kSplatSlots; k += 256u) {
-        const uint32_t tile = s_tile[k];
-        if (tile != kNoTile) raise_tile(tiles + tile, s_near[k], s_far[k]);
+    const uint32_t count = *count_ptr;
+    for (uint32_t base = blockIdx.x * 256u; base < count; base += gridDim.x * 256u) {
+        for (uint32_t k = threadIdx.x; k < kSplatSlots; k += 256u) {
+            s_tile[k] = kNoTile;
+            s_near[k] = 0u;
+            s_far[k] = 0u;
+        }
+        __syncthreads();
+        const uint32_t i = base + threadIdx.x;
+        if (i < count) splat_one(vol, fp, list[i], tiles, tiles_x, tiles_y, ctr, s_tile, s_near, s_far);
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < kSplatSlots; k += 256u) {
+            const uint32_t tile = s_tile[k];
+            if (tile != kNoTile) raise_tile(tiles + tile, s_near[k], s_far[k]);
+        }
+        __syncthreads();
     }
 }
 
@@ -604,10 +650,11 @@ __device__ __forceinline__ int span_inside(float gx, float gy, float gz, int lox
 // The pyramid folded into one table the marches read: two bits per brick, 0 = occupied, otherwise
 // 1 + the coarsest of the levels 0..2 whose cube around the brick is empty.  One load answers
 // "how far can I step from here".
-__global__ __launch_bounds__(256) void k_pack_skip(const uint32_t *__restrict__ e0, const uint32_t *__restrict__ e1,
-                                                  const uint32_t *__restrict__ e2, int nx0, int ny0, int nz0, int nx1, int ny1,
-                                                  int nx2, int ny2, uint32_t *__restrict__ skip)
+__global__ __launch_bounds__(256) void k_pack_skip(const LutInfo *__restrict__ info, const uint32_t *__restrict__ e0,
+                                                  const uint32_t *__restrict__ e1, const uint32_t *__restrict__ e2, int nx0, int ny0,
+                                                  int nz0, int nx1, int ny1, int nx2, int ny2, uint32_t *__restrict__ skip)
 {
+    if (!info->changed) return;
     const uint32_t word = blockIdx.x * 256u + threadIdx.x;
     const uint32_t bricks = (uint32_t)(nx0 * ny0 * nz0);
     if (word * 16u >= bricks) return;
@@ -1854,6 +1901,22 @@ __global__ __launch_bounds__(256) void k_replay_exact(VolumeView vol, FrameParam
             replay_ray<T, STATS, false, SHADE>(vol, fp, s_lut, dec, out, ctr, touched, e.pixel_id, tiles, tiles_x, nullptr, nullptr, e.dark_from);
         }
     });
+}
+
+// Behind the last kernel of a fast frame: tells the host, through a word of page-locked host memory the GPU
+// writes directly, how many of the frame's rays ended in the replay (the host reads the word whenever it
+// next renders and never waits for it), and optionally clears the frame's counters for the next frame
+// that uses them.  word = frame sequence number << 32 | rays queued for the replay.
+__global__ __launch_bounds__(64) void k_finish_frame(Counters *ctr, unsigned long long *host_word, uint32_t seq, int clear)
+{
+    const unsigned long long replayed = ctr->replay_count;
+    __syncthreads();   // every lane has read the count before any lane clears it
+    if (threadIdx.x == 0)
+        __hip_atomic_store(host_word, ((unsigned long long)seq << 32) | replayed, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (clear) {
+        uint32_t *words = reinterpret_cast<uint32_t *>(ctr);
+        for (uint32_t k = threadIdx.x; k < (uint32_t)(offsetof(Counters, lut_error) / sizeof(uint32_t)); k += 64u) words[k] = 0u;
+    }
 }
 
 // Number of set bits of a bit map, added to *total (counting builds: bricks touched so far).
