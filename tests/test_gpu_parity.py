@@ -131,6 +131,30 @@ def test_normalised_voxels_bit_exact(ctx, oracle, dtype, shape):
     assert cf.same_bits(ctx.read_volume_normalized(), want)
 
 
+@pytest.mark.parametrize("layers", [1, 3, 4])
+def test_ingest_strips_and_layers(ctx, oracle, monkeypatch, tmp_path, layers):
+    """The re-tiling kernel on shapes that take its aligned 16-byte loads (row length a multiple of 8) and its
+    one-by-one loads, several strips of 16 bricks with a short last one, and workgroups that walk several brick
+    layers with the shared voxel slice kept in registers (small volumes do that only when told to)."""
+    monkeypatch.setenv("VR_TEST_INGEST_LAYERS", str(layers))
+    rng = np.random.default_rng(11 + layers)
+    for dtype, shape in ((np.uint16, (37, 26, 272)), (np.uint8, (29, 19, 144)), (np.uint16, (21, 9, 141)), (np.uint8, (70, 3, 8))):
+        hi = 256 if dtype == np.uint8 else 60000
+        vox = rng.integers(0, hi, size=shape).astype(dtype)
+        ctx.upload_volume(vox)
+        want, mx = oracle.normalize(vox)
+        assert ctx.volume_info()["max_value"] == mx
+        assert cf.same_bits(ctx.read_volume_normalized(), want), (dtype, shape)
+    # big-endian slices through the same kernel (main.cpp:137-143)
+    vol = rng.integers(0, 4000, size=(19, 40, 40)).astype(np.uint16)
+    for k in range(19):
+        vol[k].astype(">u2").tofile(tmp_path / ("s.%d" % (k + 1)))
+    ctx.load_volume_data(str(tmp_path))
+    want, mx = oracle.load_slices(str(tmp_path))
+    assert ctx.volume_info()["max_value"] == mx
+    assert cf.same_bits(ctx.read_volume_normalized(), want)
+
+
 def test_normalisation_exact_for_every_u16_value(ctx, oracle):
     for mx in (65535, 63536, 5119, 3272, 257, 3):
         vox = (np.arange(65536, dtype=np.uint32) % (mx + 1)).astype(np.uint16).reshape(16, 64, 64)

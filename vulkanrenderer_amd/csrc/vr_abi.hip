@@ -44,6 +44,7 @@ struct vr_ctx {
     uint32_t *skip = nullptr;             // per brick: 2-bit code of the coarsest empty cube around it
     uint32_t *occ_list = nullptr;         // indices of the occupied bricks, for the per-tile depth ranges
     uint32_t *d_occ_count = nullptr;      // its length; stays on the device (k_splat_bricks reads it there)
+    uint32_t *d_data_max = nullptr;       // where an upload's kernels leave the largest voxel value
     uint2 *tiles = nullptr;               // per 8x8 pixel tile: depth range of the occupied bricks (fast mode)
     size_t tiles_cap = 0;
     bool tile_clip = true;
@@ -325,11 +326,15 @@ void voxels_of_bricks(int voxels, int b_lo, int b_hi, int &lo, int &hi)
     if (hi < lo) hi = lo;
 }
 
-// Re-tiles a linear device volume into bricks.  d_raw may be modified (byte swap) when
-// big_endian is set.  Frees nothing of the caller's.  With a brick box (b_lo, b_hi not null) only
-// those bricks are built and d_raw holds just the voxels they store.
+// Re-tiles a linear device volume into bricks: one pass over d_raw, which is only read (big-endian
+// values are swapped on the way).  Frees nothing of the caller's.  With a brick box (b_lo, b_hi not
+// null) only those bricks are built and d_raw holds just the voxels they store.  The old volume is given
+// up before the new one is built (the two need not fit side by side); the data maximum is known only
+// after the pass, so an upload that fails -- an allocation, a max_value below the data maximum, a volume
+// of zeros -- leaves the context without a volume (vr_render then answers VR_ERR_STATE), never with a
+// half-built one.
 template <typename T>
-int ingest_device(vr_ctx *ctx, T *d_raw, int nx, int ny, int nz, float max_value, bool big_endian, const int *b_lo = nullptr,
+int ingest_device(vr_ctx *ctx, const T *d_raw, int nx, int ny, int nz, float max_value, bool big_endian, const int *b_lo = nullptr,
                   const int *b_hi = nullptr)
 {
     const int dims[3] = {nx, ny, nz};
@@ -343,6 +348,7 @@ int ingest_device(vr_ctx *ctx, T *d_raw, int nx, int ny, int nz, float max_value
     if (sub)
         for (int k = 0; k < 3; k++) hi[k] = b_hi[k];
     if (sub && !(max_value > 0.0f)) return fail(ctx, VR_ERR_ARG, "a sub-volume needs the whole volume's maximum as max_value");
+    if (max_value > 65535.0f) return fail(ctx, VR_ERR_ARG, "max_value above 65535");
     vr::BrickSource src;
     int raw_ext[3];
     for (int k = 0; k < 3; k++) {
@@ -354,37 +360,13 @@ int ingest_device(vr_ctx *ctx, T *d_raw, int nx, int ny, int nz, float max_value
     }
     src.rx = raw_ext[0];
     src.ry = raw_ext[1];
+    src.rz = raw_ext[2];
     const size_t count = (size_t)raw_ext[0] * raw_ext[1] * raw_ext[2];
     if (count > 0 && !d_raw) return fail(ctx, VR_ERR_ARG, "null argument");
-    uint32_t data_max = 0;
-    if (count > 0) {
-        uint32_t *d_max = nullptr;
-        VR_HIP(ctx, dev_alloc(&d_max, sizeof(uint32_t)));
-        VR_HIP(ctx, hipMemsetAsync(d_max, 0, sizeof(uint32_t), ctx->stream));
-        const int blocks = (int)std::min<size_t>((count + 255) / 256, 256 * 16);
-        if (big_endian)
-            hipLaunchKernelGGL((vr::k_swap_max<T, true>), dim3(blocks), dim3(256), 0, ctx->stream, d_raw, count, d_max);
-        else
-            hipLaunchKernelGGL((vr::k_swap_max<T, false>), dim3(blocks), dim3(256), 0, ctx->stream, d_raw, count, d_max);
-        VR_HIP(ctx, hipMemcpyAsync(&data_max, d_max, sizeof data_max, hipMemcpyDeviceToHost, ctx->stream));
-        VR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        (void)dev_free(d_max);
-    }
-
-    float mx = (float)data_max;  // main.cpp:144, exact for 16-bit values
-    if (max_value > 0.0f) {
-        if (max_value < mx) return fail(ctx, VR_ERR_ARG, "max_value is below the data maximum");
-        mx = max_value;
-    }
-    if (!(mx > 0.0f)) return fail(ctx, VR_ERR_ARG, "volume is all zero: the reference would divide by zero");
-    if (mx > 65535.0f) return fail(ctx, VR_ERR_ARG, "max_value above 65535");
-
     if (sub && ctx->shading) return fail(ctx, VR_ERR_STATE, "shading is on: a sub-volume's apron does not hold the neighbours the gradient reads");
     const size_t brick_count = (size_t)(hi[0] - lo[0]) * (size_t)(hi[1] - lo[1]) * (size_t)(hi[2] - lo[2]);
     if (brick_count >= (1ull << 31)) return fail(ctx, VR_ERR_ARG, "volume too large");
-    // From here on the old volume is gone.  The upload is all or nothing: when any step below fails
-    // the context is left without a volume (vr_render then answers VR_ERR_STATE), never with a
-    // half-built one whose tables are null.
+    // From here on the old volume is gone.
     release_volume(ctx);
     ctx->nx = nx; ctx->ny = ny; ctx->nz = nz;
     ctx->nbx = hi[0] - lo[0];
@@ -394,10 +376,6 @@ int ingest_device(vr_ctx *ctx, T *d_raw, int nx, int ny, int nz, float max_value
     for (int k = 0; k < 3; k++) ctx->brick_lo[k] = lo[k];
     ctx->brick_count = brick_count;
     ctx->dtype = (int)sizeof(T);
-    ctx->max_value = mx;
-    // v / max == fma(v, inv_hi, v * inv_lo) bit for bit for all integers 0 <= v <= max <= 65535
-    ctx->inv_hi = 1.0f / mx;
-    ctx->inv_lo = (float)(1.0 / (double)mx - (double)ctx->inv_hi);
     hipError_t err = volume_alloc(ctx, &ctx->bricks, brick_count * vr::kBrickElems * sizeof(T));
     if (err == hipSuccess) err = volume_alloc(ctx, &ctx->cells, brick_count * sizeof(uint32_t));
     if (err == hipSuccess) err = volume_alloc(ctx, &ctx->touched, ((brick_count + 31) / 32) * sizeof(uint32_t));
@@ -411,18 +389,64 @@ int ingest_device(vr_ctx *ctx, T *d_raw, int nx, int ny, int nz, float max_value
     if (err == hipSuccess) err = volume_alloc(ctx, &ctx->micro, brick_count * sizeof(unsigned long long));
     if (err == hipSuccess) err = volume_alloc(ctx, &ctx->skip, ((brick_count + 15) / 16) * sizeof(uint32_t));
     if (err == hipSuccess) err = volume_alloc(ctx, &ctx->occ_list, brick_count * sizeof(uint32_t));
+    uint32_t data_max = 0;
+    if (err == hipSuccess) err = hipMemsetAsync(ctx->d_data_max, 0, sizeof(uint32_t), ctx->stream);
     if (err == hipSuccess) {
-        const unsigned brick_blocks = (unsigned)std::min<size_t>((brick_count + 3) / 4, 1u << 20);   // four waves, a brick each
-        hipLaunchKernelGGL((vr::k_build_bricks<T>), dim3(brick_blocks), dim3(256), 0, ctx->stream, (const T *)d_raw,
-                           (T *)ctx->bricks, ctx->cells, nx, ny, nz, ctx->nbx, ctx->nby, (uint32_t)brick_count, src);
-        err = hipGetLastError();
+        const int strips = (ctx->nbx + vr::kStrip - 1) / vr::kStrip;
+        // a workgroup walks kIngestLayers brick layers of its strip, fewer when that leaves the chip short of workgroups
+        const size_t columns = (size_t)strips * (size_t)ctx->nby;
+        int z_steps = vr::kIngestLayers;
+        // test hook: small volumes walk several layers too (by themselves they take one per workgroup)
+        const char *forced = std::getenv("VR_TEST_INGEST_LAYERS");
+        if (forced && std::atoi(forced) > 0) z_steps = std::atoi(forced);
+        while (!forced && z_steps > 1 && columns * (size_t)((ctx->nbz + z_steps - 1) / z_steps) < 4096) z_steps /= 2;
+        const size_t blocks_total = columns * (size_t)((ctx->nbz + z_steps - 1) / z_steps);
+        const unsigned grid = (unsigned)(((blocks_total + 7) / 8) * 8);
+        // rows of raw start on multiples of 8 voxels when its row length is one and the buffer itself is aligned
+        const int vec_ok = (src.rx % 8 == 0) && (reinterpret_cast<uintptr_t>(d_raw) % (8 * sizeof(T)) == 0);
+        // where the strips' first stored voxel sits in its group of 8 raw voxels: bricks start two voxels before a
+        // multiple of 8, raw at voxel 0 of the volume or at a box's first stored voxel
+        const int xo = (lo[0] * vr::kBrick - vr::kPad - src.v0[0]) & 7;
+        auto launch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, ctx->stream, d_raw, (T *)ctx->bricks, ctx->cells, ctx->nbx, ctx->nby,
+                               ctx->nbz, src, strips, z_steps, (uint32_t)blocks_total);
+        };
+        if (xo == 6) {
+            if (big_endian) vec_ok ? launch(vr::k_ingest_bricks<T, true, 6, true>) : launch(vr::k_ingest_bricks<T, true, 6, false>);
+            else vec_ok ? launch(vr::k_ingest_bricks<T, false, 6, true>) : launch(vr::k_ingest_bricks<T, false, 6, false>);
+        } else if (xo == 0) {
+            if (big_endian) vec_ok ? launch(vr::k_ingest_bricks<T, true, 0, true>) : launch(vr::k_ingest_bricks<T, true, 0, false>);
+            else vec_ok ? launch(vr::k_ingest_bricks<T, false, 0, true>) : launch(vr::k_ingest_bricks<T, false, 0, false>);
+        } else {
+            err = hipErrorInvalidValue;   // cannot happen: voxels_of_bricks yields one of the two
+        }
+        hipLaunchKernelGGL(vr::k_cells_max, dim3((unsigned)std::min<size_t>((brick_count + 255) / 256, 1024)), dim3(256), 0, ctx->stream,
+                           ctx->cells, (uint32_t)brick_count, ctx->d_data_max);
+        if (err == hipSuccess) err = hipGetLastError();
     }
+    if (err == hipSuccess) err = hipMemcpyAsync(&data_max, ctx->d_data_max, sizeof data_max, hipMemcpyDeviceToHost, ctx->stream);
     if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
     if (err != hipSuccess) {
         (void)hipGetLastError();   // an allocation failure is not sticky; clear it for the calls that follow
         release_volume(ctx);
         return fail(ctx, VR_ERR_HIP, std::string("volume upload: ") + hipGetErrorString(err));
     }
+    float mx = (float)data_max;  // main.cpp:144, exact for 16-bit values
+    if (max_value > 0.0f) {
+        if (max_value < mx) {
+            release_volume(ctx);
+            return fail(ctx, VR_ERR_ARG, "max_value is below the data maximum");
+        }
+        mx = max_value;
+    }
+    if (!(mx > 0.0f)) {
+        release_volume(ctx);
+        return fail(ctx, VR_ERR_ARG, "volume is all zero: the reference would divide by zero");
+    }
+    ctx->max_value = mx;
+    // v / max == fma(v, inv_hi, v * inv_lo) bit for bit for all integers 0 <= v <= max <= 65535
+    ctx->inv_hi = 1.0f / mx;
+    ctx->inv_lo = (float)(1.0 / (double)mx - (double)ctx->inv_hi);
     ctx->occupancy_dirty = true;
     ctx->occupancy_force = true;
     ctx->table_epoch++;
@@ -677,6 +701,7 @@ int vr_create(int device, vr_ctx **out)
         dev_alloc(&ctx->lut_info, sizeof(vr::LutInfo)) != hipSuccess ||
         dev_alloc(&ctx->occ, 6 * sizeof(int)) != hipSuccess ||
         dev_alloc(&ctx->d_occ_count, sizeof(uint32_t)) != hipSuccess ||
+        dev_alloc(&ctx->d_data_max, sizeof(uint32_t)) != hipSuccess ||
         hipMemset(ctx->d_occ_count, 0, sizeof(uint32_t)) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->occ_ready, hipEventDisableTiming) != hipSuccess ||
         hipEventRecord(ctx->occ_ready, ctx->stream) != hipSuccess ||
@@ -756,6 +781,7 @@ int vr_destroy(vr_ctx *ctx)
     if (ctx->lut_info) (void)dev_free(ctx->lut_info);
     if (ctx->occ) (void)dev_free(ctx->occ);
     if (ctx->d_occ_count) (void)dev_free(ctx->d_occ_count);
+    if (ctx->d_data_max) (void)dev_free(ctx->d_data_max);
     if (ctx->occ_ready) (void)hipEventDestroy(ctx->occ_ready);
     if (ctx->probe_word) (void)hipHostFree(ctx->probe_word);
     if (ctx->tiles) (void)dev_free(ctx->tiles);
@@ -841,8 +867,8 @@ int vr_upload_volume_device(vr_ctx *ctx, const void *d_voxels, int dtype, int nx
     if (!ctx || !d_voxels) return fail(ctx, VR_ERR_ARG, "null argument");
     if (int rc = check_dims(ctx, dtype, nx, ny, nz)) return rc;
     if (int rc = bind(ctx)) return rc;
-    if (dtype == VR_DTYPE_U8) return ingest_device<uint8_t>(ctx, (uint8_t *)d_voxels, nx, ny, nz, max_value, false);
-    return ingest_device<uint16_t>(ctx, (uint16_t *)d_voxels, nx, ny, nz, max_value, false);
+    if (dtype == VR_DTYPE_U8) return ingest_device<uint8_t>(ctx, (const uint8_t *)d_voxels, nx, ny, nz, max_value, false);
+    return ingest_device<uint16_t>(ctx, (const uint16_t *)d_voxels, nx, ny, nz, max_value, false);
 }
 
 int vr_upload_volume(vr_ctx *ctx, const void *voxels, int dtype, int nx, int ny, int nz, float max_value)
@@ -1640,8 +1666,8 @@ int vr_upload_subvolume_device(vr_ctx *ctx, const void *d_voxels, int dtype, int
     if (!ctx || !brick_lo || !brick_hi) return fail(ctx, VR_ERR_ARG, "null argument");
     if (int rc = check_dims(ctx, dtype, nx, ny, nz)) return rc;
     if (int rc = bind(ctx)) return rc;
-    if (dtype == VR_DTYPE_U8) return ingest_device<uint8_t>(ctx, (uint8_t *)d_voxels, nx, ny, nz, max_value, false, brick_lo, brick_hi);
-    return ingest_device<uint16_t>(ctx, (uint16_t *)d_voxels, nx, ny, nz, max_value, false, brick_lo, brick_hi);
+    if (dtype == VR_DTYPE_U8) return ingest_device<uint8_t>(ctx, (const uint8_t *)d_voxels, nx, ny, nz, max_value, false, brick_lo, brick_hi);
+    return ingest_device<uint16_t>(ctx, (const uint16_t *)d_voxels, nx, ny, nz, max_value, false, brick_lo, brick_hi);
 }
 
 static int frame_params(vr_ctx *ctx, int width, int height, vr::FrameParams &fp)

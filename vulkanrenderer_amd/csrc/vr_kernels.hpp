@@ -477,77 +477,208 @@ __global__ __launch_bounds__(256) void k_lut_update(float *__restrict__ lut, con
 }
 
 // ---- ingest --------------------------------------------------------------------------------
-// Maximum of the raw voxels (loadVolumeData tracks it while reading, main.cpp:144); for
-// big-endian input the bytes are swapped in place first (main.cpp:141-143).
-template <typename T, bool SWAP>
-__global__ __launch_bounds__(256) void k_swap_max(T *__restrict__ raw, size_t count, uint32_t *result)
+// One pass from the linear volume (x fastest, then y, then slice: main.cpp:41,131-146) to bricks: the
+// byte swap of big-endian input (main.cpp:141-143), the re-tiling and the (min,max) macrocell of each
+// brick; the data maximum loadVolumeData tracks while reading (main.cpp:144) is the largest macrocell
+// maximum (k_cells_max), so the raw voxels are read once and never written.
+//
+// A workgroup takes a strip of kStrip bricks along x and walks it through `z_steps` brick layers.  LDS
+// holds the strip's bricks in the layout they have in memory.  Per layer every lane loads 8 voxels of a
+// raw row at a time (one 16-byte load where the raw rows are aligned for it) and scatters them to the one
+// or two bricks that store them; then each brick leaves LDS as it stands, 16 bytes per lane, one wave per
+// brick, 1472 (u16) contiguous bytes per brick -- the 9^3 voxels; the 32 elements of padding behind them are
+// never read and never written -- with the macrocell folded from the same registers.  The last voxel slice of a layer is the first of the next (the apron):
+// the lanes that loaded it keep it in registers and scatter it again, so only 8 slices are read per
+// further layer.  Voxel rows shared with the strips next to this one in x and y are read by both; the
+// grid is dealt so that such neighbours run on one XCD (workgroups b and b + 8 sit on the same XCD).
+//
+// The bricks built are the nbx x nby x nbz box of the volume's brick grid that starts at brick `b0`;
+// `raw` holds the voxels [v0, v0 + (rx, ry, rz)) of the volume, which must cover every voxel of the
+// volume those bricks store (what lies outside raw is outside the volume: zeros).
+struct BrickSource {
+    int b0[3];       // first brick of the box
+    int v0[3];       // first voxel held by raw
+    int rx, ry, rz;  // extent of raw in voxels
+};
+constexpr int kStrip = 16;                // bricks along x per workgroup (32: LDS for half as many workgroups per CU, 40 % slower)
+constexpr int kIngestLayers = 4;          // brick layers a workgroup walks (1: every layer's first slice read twice; 16 and more:
+                                          // neighbours drift apart and the rows they share leave the L2 in between)
+constexpr int kStripGroups = kStrip + 1;  // aligned groups of 8 raw voxels that hold a strip's 8 * kStrip + 1 columns
+// LDS pitch of a brick: 8 elements more than in memory, so that the lanes of a wave, which scatter the same
+// row of neighbouring bricks, do not all hit one bank
+constexpr int kLdsBrick = kBrickElems + 8;
+
+// 8 voxels as loaded: kWords dwords.  Element i of them.
+template <typename T>
+__device__ __forceinline__ uint32_t voxel_of(const uint32_t *w, int i)
+{
+    return sizeof(T) == 2 ? (w[i >> 1] >> (16 * (i & 1))) & 0xffffu : (w[i >> 2] >> (8 * (i & 3))) & 0xffu;
+}
+
+// XO: column of the strip's first stored voxel inside its aligned group of 8 raw voxels -- 6 when raw starts
+// at voxel 0 of the volume (bricks start two voxels before a multiple of 8), 0 when raw starts at a box's
+// first stored voxel.  Element i of group g then belongs to brick g - 1 (cell 8 - XO + i) for i <= XO and to
+// brick g (cell i - XO) for i >= XO; element XO is the apron voxel both store.
+// VEC: the rows of raw start on multiples of 8 voxels in memory (row length a multiple of 8, buffer aligned),
+// so a group of 8 lies wholly inside raw or wholly outside and is one load; without it the voxels are loaded
+// one by one (odd-sized volumes: small ones).
+template <typename T, bool SWAP, int XO, bool VEC>
+__global__ __launch_bounds__(256, VEC ? 6 : 1) void k_ingest_bricks(const T *__restrict__ raw, T *__restrict__ bricks,
+                                                                   uint32_t *__restrict__ cells, int nbx, int nby, int nbz,
+                                                                   BrickSource src, int strips, int z_steps, uint32_t blocks_total)
+{
+    constexpr int kWords = (int)sizeof(T) * 2;   // dwords that hold 8 voxels
+    constexpr int kVoxels = kRow * kRow * kRow;
+    // 8-element pieces of a brick that are written: those that hold voxels (the last has one voxel and 7 zeros);
+    // the 32 elements of padding behind them are never read by anything and stay as allocated
+    constexpr int kPieces = (kVoxels + 7) / 8;
+    __shared__ __align__(16) T s_brick[kStrip * kLdsBrick];
+    const uint32_t per_xcd = gridDim.x >> 3;   // the grid is a multiple of 8 workgroups
+    const uint32_t logical = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (logical >= blocks_total) return;
+    const int strip = (int)(logical % (uint32_t)strips);
+    const int by = (int)((logical / (uint32_t)strips) % (uint32_t)nby);
+    const int zc = (int)(logical / (uint32_t)(strips * nby));
+    const int bx0 = strip * kStrip;
+    const int kvalid = nbx - bx0 < kStrip ? nbx - bx0 : kStrip;
+    const int bz_begin = zc * z_steps, bz_end = bz_begin + z_steps < nbz ? bz_begin + z_steps : nbz;
+    const int y0 = (by + src.b0[1]) * kBrick - kPad - src.v0[1];              // raw row of the strip's first stored row
+    const int xs = (bx0 + src.b0[0]) * kBrick - kPad - src.v0[0] - XO;        // raw column of the strip's first group (a multiple of 8)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+
+    // the 39 elements of padding behind the 9^3 voxels of every brick are zero and stay so
+    for (int i = threadIdx.x; i < kStrip * (kBrickElems - kVoxels); i += 256)
+        s_brick[(i / (kBrickElems - kVoxels)) * kLdsBrick + kVoxels + i % (kBrickElems - kVoxels)] = (T)0;
+
+    // 8 voxels of raw row (iy, iz) from column x on, zeros outside raw
+    auto load_group = [&](int iy, int iz, int x, uint32_t *w) {
+#pragma unroll
+        for (int k = 0; k < kWords; k++) w[k] = 0u;
+        if ((unsigned)iy < (unsigned)src.ry && (unsigned)iz < (unsigned)src.rz) {
+            const T *row = raw + ((size_t)iz * (size_t)src.ry + (size_t)iy) * (size_t)src.rx;
+            if (VEC) {
+                if (x >= 0 && x + 8 <= src.rx) __builtin_memcpy(w, __builtin_assume_aligned(row + x, 8 * sizeof(T)), 8 * sizeof(T));
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int xi = x + i;
+                    const uint32_t v = (unsigned)xi < (unsigned)src.rx ? (uint32_t)row[xi] : 0u;
+                    w[i * (int)sizeof(T) / 4] |= v << (8 * ((i * (int)sizeof(T)) & 3));
+                }
+            }
+            if (SWAP) {
+#pragma unroll
+                for (int k = 0; k < kWords; k++) w[k] = ((w[k] & 0x00ff00ffu) << 8) | ((w[k] >> 8) & 0x00ff00ffu);
+            }
+        }
+    };
+    // the 8 voxels of group g into row r (= lz * 9 + ly) of the bricks that store them
+    auto scatter_group = [&](const uint32_t *w, int r, int g) {
+        T *to_prev = s_brick + (g - 1) * kLdsBrick + r * kRow + (kBrick - XO);   // element i -> cell 8 - XO + i of brick g - 1
+        T *to_own = s_brick + g * kLdsBrick + r * kRow - XO;                       // element i -> cell i - XO of brick g
+        if (g >= 1) {
+#pragma unroll
+            for (int i = 0; i <= XO; i++) to_prev[i] = (T)voxel_of<T>(w, i);
+        }
+        if (g < kvalid) {
+#pragma unroll
+            for (int i = XO; i < 8; i++) to_own[i] = (T)voxel_of<T>(w, i);
+        }
+    };
+
+    // the rows of slice 8 come first in a layer's list of loads: 9 rows x kStripGroups groups, one per thread,
+    // kept for the next layer, where they are slice 0
+    const bool keeper = threadIdx.x < kRow * kStripGroups;
+    const int keep_ly = threadIdx.x / kStripGroups, keep_g = threadIdx.x % kStripGroups;
+    uint32_t keep[kWords];
+    for (int bz = bz_begin, step = 0; bz < bz_end; bz++, step++) {
+        const int z0 = (bz + src.b0[2]) * kBrick - kPad - src.v0[2];
+        constexpr int kItems = (kBrick - 1) * kRow * kStripGroups;   // rows of slices 1..7
+        if (keeper && keep_g <= kvalid) {
+            if (step == 0) load_group(y0 + keep_ly, z0, xs + keep_g * 8, keep);
+            scatter_group(keep, keep_ly, keep_g);
+            load_group(y0 + keep_ly, z0 + kBrick, xs + keep_g * 8, keep);
+            scatter_group(keep, kBrick * kRow + keep_ly, keep_g);
+        }
+        for (int idx = threadIdx.x; idx < kItems; idx += 256) {
+            const int rr = idx / kStripGroups, g = idx - rr * kStripGroups;
+            if (g > kvalid) continue;   // a short last strip
+            uint32_t w[kWords];
+            load_group(y0 + rr % kRow, z0 + 1 + rr / kRow, xs + g * 8, w);
+            scatter_group(w, (1 + rr / kRow) * kRow + rr % kRow, g);
+        }
+        __syncthreads();
+        for (int k = wave; k < kvalid; k += 4) {
+            const uint32_t brick = ((uint32_t)bz * (uint32_t)nby + (uint32_t)by) * (uint32_t)nbx + (uint32_t)(bx0 + k);
+            T *out = bricks + (size_t)brick * kBrickElems;
+            uint32_t mn = 0xffffffffu, mx = 0u;
+            typedef unsigned short pair_t __attribute__((ext_vector_type(2)));
+            pair_t pair_mn = {0xffff, 0xffff}, pair_mx = {0, 0};   // u16: two voxels per dword folded at once
+#pragma unroll
+            for (int pass = 0; pass < 2; pass++) {
+                const int j = pass * 64 + lane;      // 8-element piece of the brick's 768
+                if (j < kPieces) {
+                    uint32_t w[kWords];
+                    __builtin_memcpy(w, __builtin_assume_aligned(s_brick + k * kLdsBrick + j * 8, 8 * sizeof(T)), 8 * sizeof(T));
+                    // streamed past the L2, which then keeps the raw rows the neighbouring strips read again
+                    typedef uint32_t vec_t __attribute__((ext_vector_type(kWords)));
+                    vec_t v;
+#pragma unroll
+                    for (int q = 0; q < kWords; q++) v[q] = w[q];
+                    __builtin_nontemporal_store(v, reinterpret_cast<vec_t *>(out + j * 8));
+                    const int valid = kVoxels - j * 8;   // elements of the piece that are voxels, not padding
+                    if (sizeof(T) == 2 && valid >= 8) {
+#pragma unroll
+                        for (int q = 0; q < kWords; q++) {
+                            pair_t v;
+                            __builtin_memcpy(&v, &w[q], 4);
+                            pair_mn = __builtin_elementwise_min(pair_mn, v);
+                            pair_mx = __builtin_elementwise_max(pair_mx, v);
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 8; i++) {
+                            const uint32_t v = voxel_of<T>(w, i);
+                            if (i < valid) {
+                                mn = v < mn ? v : mn;
+                                mx = v > mx ? v : mx;
+                            }
+                        }
+                    }
+                }
+            }
+            if (sizeof(T) == 2) {
+                const uint32_t a = pair_mn[0] < pair_mn[1] ? pair_mn[0] : pair_mn[1], b = pair_mx[0] > pair_mx[1] ? pair_mx[0] : pair_mx[1];
+                mn = a < mn ? a : mn;
+                mx = b > mx ? b : mx;
+            }
+            // one reduction for both: the halves of (max, 65535 - min) are folded by maxima
+            uint32_t both = (mx << 16) | (0xffffu - (mn & 0xffffu));
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint32_t other = __shfl_xor(both, o);
+                const uint32_t hi = (other >> 16) > (both >> 16) ? (other >> 16) : (both >> 16);
+                const uint32_t lo = (other & 0xffffu) > (both & 0xffffu) ? (other & 0xffffu) : (both & 0xffffu);
+                both = (hi << 16) | lo;
+            }
+            if (lane == 0) cells[brick] = (0xffffu - (both & 0xffffu)) | (both & 0xffff0000u);
+        }
+        __syncthreads();
+    }
+}
+
+// Largest macrocell maximum = the data maximum (every voxel is stored by some brick).
+__global__ __launch_bounds__(256) void k_cells_max(const uint32_t *__restrict__ cells, uint32_t count, uint32_t *result)
 {
     uint32_t mx = 0;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
-        uint32_t v = raw[i];
-        if (SWAP) {
-            v = ((v >> 8) | (v << 8)) & 0xffffu;
-            raw[i] = (T)v;
-        }
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
+        const uint32_t v = cells[i] >> 16;
         mx = v > mx ? v : mx;
     }
     for (int o = 32; o > 0; o >>= 1) {
         const uint32_t other = __shfl_xor(mx, o);
         mx = other > mx ? other : mx;
     }
-    if ((threadIdx.x & 63) == 0) atomicMax(result, mx);
-}
-
-// Re-tiles the linear volume (x fastest, then y, then slice: main.cpp:41,131-146) into bricks and
-// builds the (min,max) macrocell of each brick.  One block per brick.
-// The bricks built are the nbx x nby x (brick_count / (nbx*nby)) box of the volume's brick grid
-// that starts at brick `b0`; `raw` holds the voxels [v0, v0 + (rx, ry, ..)) of the nx x ny x nz
-// volume, which must cover every voxel of the volume those bricks store.
-struct BrickSource {
-    int b0[3];   // first brick of the box
-    int v0[3];   // first voxel held by raw
-    int rx, ry;  // row and column count of raw
-};
-template <typename T>
-__global__ __launch_bounds__(256) void k_build_bricks(const T *__restrict__ raw, T *__restrict__ bricks,
-                                                     uint32_t *__restrict__ cells, int nx, int ny, int nz,
-                                                     int nbx, int nby, uint32_t brick_count, BrickSource src)
-{
-    // One wave per brick and pass: each lane gathers 12 of the brick's 768 elements (all loads in flight
-    // together), writes them, and the wave folds minimum and maximum with shuffles -- no barrier, no LDS.
-    const int lane = threadIdx.x & 63;
-    const uint32_t waves = gridDim.x * 4u;
-    for (uint32_t brick = blockIdx.x * 4u + (threadIdx.x >> 6); brick < brick_count; brick += waves) {
-        const int bx = brick % nbx, by = (brick / nbx) % nby, bz = brick / (nbx * nby);
-        const int x0 = (bx + src.b0[0]) * kBrick - kPad, y0 = (by + src.b0[1]) * kBrick - kPad, z0 = (bz + src.b0[2]) * kBrick - kPad;
-        T *dst = bricks + (size_t)brick * kBrickElems;
-        uint32_t v[kBrickElems / 64];
-#pragma unroll
-        for (int k = 0; k < kBrickElems / 64; k++) {
-            const int e = k * 64 + lane;
-            const int lx = e % kRow, ly = (e / kRow) % kRow, lz = e / kSlice;
-            const int ix = x0 + lx, iy = y0 + ly, iz = z0 + lz;
-            v[k] = 0;
-            if (e < kRow * kRow * kRow && (unsigned)ix < (unsigned)nx && (unsigned)iy < (unsigned)ny && (unsigned)iz < (unsigned)nz)
-                v[k] = raw[((size_t)(iz - src.v0[2]) * src.ry + (iy - src.v0[1])) * src.rx + (ix - src.v0[0])];
-        }
-        uint32_t mn = 0xffffffffu, mx = 0;
-#pragma unroll
-        for (int k = 0; k < kBrickElems / 64; k++) {
-            const int e = k * 64 + lane;
-            dst[e] = (T)v[k];
-            if (e < kRow * kRow * kRow) {      // the 39 elements of padding behind the 9^3 voxels stay out of the range
-                mn = v[k] < mn ? v[k] : mn;
-                mx = v[k] > mx ? v[k] : mx;
-            }
-        }
-        for (int o = 32; o > 0; o >>= 1) {
-            const uint32_t a = __shfl_xor(mn, o), b = __shfl_xor(mx, o);
-            mn = a < mn ? a : mn;
-            mx = b > mx ? b : mx;
-        }
-        if (lane == 0) cells[brick] = mn | (mx << 16);
-    }
+    if ((threadIdx.x & 63) == 0 && mx > 0u) atomicMax(result, mx);
 }
 
 // float(v) / float(max) for every voxel, back in linear order: what the reference keeps in
