@@ -101,6 +101,22 @@ def cpu_baseline(config="c2", threads=0):
                                                                  ", best of %d" % reps if reps > 1 else "")}
 
 
+def frame_graphs(step, kind):
+    """Control graphs of frame `step` for --tf-every-frame: the reference rebuilds its table from the editor's
+    graphs every frame (main.cpp:800-804, 643-736); `same` hands over unchanged graphs, `values` moves the
+    opacity of the third alpha point (table values change, the set of transparent entries does not), `threshold`
+    moves the second alpha point along x (the transparent range itself moves, so the occupancy tables follow; it
+    stays between the phantom's tissue levels 0.2 and 0.3, i.e. x in (97, 145), so that the object on screen --
+    and with it the work of a frame -- is the static run's and the difference is the cost of the table change)."""
+    if kind == "values":
+        a3 = 0.05 + 0.04 * math.sin(2.0 * math.pi * step / 60.0)
+        return TF_GRAPHS[:3] + [list(zip(TF_X, (0, 0, a3, .6)))]
+    if kind == "threshold":
+        x2 = 120.0 + 18.0 * math.sin(2.0 * math.pi * step / 90.0)
+        return TF_GRAPHS[:3] + [list(zip((0.0, x2, 300.0, 483.0), (0, 0, .05, .6)))]
+    return TF_GRAPHS
+
+
 def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -125,6 +141,10 @@ def parse_args(argv=None):
     ap.add_argument("--table", choices=("benchmark", "translucent"), default="benchmark",
                     help="transfer function: the benchmark's 4-point table, or one with low alpha everywhere (not the headline "
                          "workload: every tap of every ray has to be marched)")
+    ap.add_argument("--tf-every-frame", choices=("off", "same", "values", "threshold"), default="same",
+                    help="hand the control graphs to the library in front of every frame, as the reference's renderCommands does "
+                         "(main.cpp:800-804): the same graphs (default: the reference's loop with an idle editor), graphs whose "
+                         "opacity values move, graphs whose transparent range moves; off: table set once in the set-up")
     ap.add_argument("--stats-frames", type=int, default=12, help="frames measured with counters for the roofline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tune", action="store_true",
@@ -263,7 +283,12 @@ def run_sort_first(args, su):
     torch.cuda.synchronize()     # the fill ran on torch's stream, the frames are written on the context's
     gathered = [None] * len(sf.locals)   # per band buffer: event after the gather that last read it
 
+    base_graphs = TRANSLUCENT_GRAPHS if args.table == "translucent" else TF_GRAPHS
+    tf_kind = [args.tf_every_frame]
+
     def frame(step):
+        if tf_kind[0] != "off":   # the reference's frame: table, uniforms, dispatch (main.cpp:800-828)
+            ctx.update_transfer_function(base_graphs if tf_kind[0] == "same" else frame_graphs(step, tf_kind[0]))
         ctx.set_camera(*su.camera(step))
         if world == 1:
             ctx.render_bands(w, h, 0, 1, ptr=targets[step % 3].data_ptr())
@@ -288,6 +313,28 @@ def run_sort_first(args, su):
     su.fence(ctx)
     elapsed = su.max_over_ranks(time.perf_counter() - t0)
     kernel_ms = ctx.march_kernel_times(min(args.steps, 1024))
+
+    # the same loop with the table set once, and with graphs that change every frame (untimed extras, shorter runs)
+    tf_extras = None
+    if world == 1 and args.table == "benchmark":
+        tf_extras = {args.tf_every_frame: elapsed / args.steps * 1e3}
+        short = min(args.steps, 120)
+        for kind in ("off", "same", "values", "threshold"):
+            if kind == args.tf_every_frame:
+                continue
+            tf_kind[0] = kind
+            for i in range(args.warmup):
+                frame(i)
+            su.fence(ctx)
+            t1 = time.perf_counter()
+            for i in range(short):
+                frame(i)
+            su.fence(ctx)
+            tf_extras[kind] = (time.perf_counter() - t1) / short * 1e3
+        tf_kind[0] = args.tf_every_frame
+        ctx.update_transfer_function(base_graphs, reset_state=True)
+        tf_extras = {"ms_per_step": tf_extras, "frames": {k: (args.steps if k == args.tf_every_frame else short) for k in tf_extras},
+                     "timed_region_uses": args.tf_every_frame}
 
     # latency of single frames (untimed pass, one frame at a time on one stream): the spread over the views
     latency = None
@@ -392,17 +439,20 @@ def run_sort_first(args, su):
             "ms_per_step": elapsed / args.steps * 1e3,
             "frames_per_s": args.steps / elapsed,
             "single_frame_ms": latency,
+            "tf_every_frame": tf_extras,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": su.workload(args, ""),
+                "workload": su.workload(args, "" if args.tf_every_frame == "off" else ", control graphs handed to the library every frame (%s)" %
+                                        {"same": "unchanged", "values": "opacity values moving", "threshold": "transparent range moving"}[args.tf_every_frame]),
                 "name": args.config,
                 "volume": [n, n, n], "image": [w, h], "samples_per_ray": samples, "mode": args.mode,
                 "parallelism": "sort-first x%d (16-row bands, replicated volume, RCCL gather)" % world if world > 1 else "single GPU",
                 "frames_in_flight": 2,
+                "tf_every_frame": args.tf_every_frame,
                 "shading": bool(args.shading),
                 "lane_budget": lane_budget,
                 "setup_s": round(t_setup, 2),
