@@ -175,6 +175,24 @@ int vr_render_rect(vr_ctx *ctx, int width, int height, int x0, int y0, int x1, i
 int vr_render_static(vr_ctx *ctx, int width, int height, uint8_t *d_out);
 int vr_static_max_pixels(void);
 
+/* Frames for a consumer on the host.  The reference hands every frame on with a device-side image copy into
+ * the image its window presents (copyImage raycastedImage -> presentedImgui, main.cpp:903-909); a host
+ * program that presents, encodes or stores frames needs them in host memory instead, and vr_render with a
+ * host pointer pays a synchronous copy into pageable memory for that (several times the render time at 4K).
+ * vr_render_mapped renders a frame (current mode; with vr_set_pipeline(ctx, 2) in flight like any other)
+ * into one of three slots the context owns -- a device image and a page-locked host image each -- and
+ * enqueues the copy to the host on a stream of its own, so the copy of frame n runs under the march of
+ * frame n + 1; the call returns at once with the slot in *frame_id.  vr_map_frame waits until that frame has
+ * arrived and yields its width*height*4 bytes (RGBA8, row-major) in page-locked memory, valid until
+ * vr_unmap_frame; a slot is used again by the third vr_render_mapped after it, which answers VR_ERR_STATE
+ * while the slot is still mapped.  Typical loop: render_mapped(n); map(n - 1); consume; unmap(n - 1).
+ * Measured at 3840x2160 on the 2048^3 phantom (examples/orbit): 1.58 ms per frame on the host with one frame
+ * at a time, against 6.4 ms through vr_render's host pointer; with two frames in flight the copy ends up in a
+ * chain with the previous frame's finishing kernels and a frame takes 2.5 ms, so leave the pipeline at 1 here. */
+int vr_render_mapped(vr_ctx *ctx, int width, int height, int *frame_id);
+int vr_map_frame(vr_ctx *ctx, int frame_id, const uint8_t **pixels);
+int vr_unmap_frame(vr_ctx *ctx, int frame_id);
+
 /* Frames in flight (no counterpart in the reference, which waits on a fence every frame,
  * Source/VulkanApplication.cpp:560-562).  With frames_in_flight == 2, VR_MODE_FAST frames rendered
  * into device memory without a stats pointer are pipelined: the kernels that finish a frame (the few

@@ -774,15 +774,60 @@ def test_histogram_of_the_phantom(ctx, oracle):
 
 # ---- the C++ host program on the C ABI ------------------------------------------------------------
 
-def test_orbit_example_writes_the_checkers_frames(oracle, tmp_path):
+@pytest.mark.parametrize("in_flight", [1, 2])
+def test_mapped_frames_for_a_host_consumer(ctx, vr, oracle, in_flight):
+    """vr_render_mapped / vr_map_frame: an orbit whose frames are copied into the context's page-locked ring while
+    the next frame renders; every frame equals the one vr_render returns, in both fast and reference-order mode,
+    with one and with two frames in flight, across a change of image size; a slot that is still mapped when
+    its turn comes again is refused."""
+    ctx.upload_volume(oracle.phantom(56, np.uint16))
+    ctx.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+    ctx.set_sampling(160)
+    cams = [(math.radians(-60.0 + 25.0 * k), math.radians(10.0 + 4.0 * k)) for k in range(7)]
+    for mode, (w, h) in ((1, (200, 144)), (0, (120, 72)), (1, (333, 211))):
+        ctx.set_mode(mode)
+        ctx.set_pipeline(1)
+        want = []
+        for cam in cams:
+            ctx.set_camera(*cam)
+            want.append(ctx.render(w, h))
+        ctx.set_pipeline(in_flight)
+        previous = None
+        for k in range(len(cams) + 1):
+            slot = None
+            if k < len(cams):
+                ctx.set_camera(*cams[k])
+                slot = ctx.render_mapped(w, h)
+            if previous is not None:
+                got = ctx.map_frame(previous, w, h)
+                assert np.array_equal(got, want[k - 1]), (mode, k - 1, cf.frame_report(got, want[k - 1]))
+                ctx.unmap_frame(previous)
+            previous = slot
+    ctx.set_pipeline(1)
+    # three slots: with one left mapped, the third render after it has nowhere to go
+    ctx.set_mode(1)
+    first = ctx.render_mapped(64, 64)
+    ctx.map_frame(first, 64, 64)
+    ctx.render_mapped(64, 64)
+    ctx.render_mapped(64, 64)
+    with pytest.raises(vr.VrError, match="mapped"):
+        ctx.render_mapped(64, 64)
+    ctx.unmap_frame(first)
+    ctx.unmap_frame(ctx.render_mapped(64, 64))
+    with pytest.raises(vr.VrError):
+        ctx.map_frame(7, 64, 64)
+
+
+@pytest.mark.parametrize("hand_off", ["mapped", "pageable"])
+def test_orbit_example_writes_the_checkers_frames(oracle, tmp_path, hand_off):
     import subprocess
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "orbit")
     if not os.path.exists(exe):
         pytest.fail("examples/orbit is not built: make -C vulkanrenderer_amd/csrc")
     w, h, n, samples, frames = 96, 80, 48, 120, 3
     res = subprocess.run([exe, "--phantom", str(n), "--size", "%dx%d" % (w, h), "--frames", str(frames), "--samples", str(samples),
-                          "--start", "10", "--step", "40", "--elevation", "25", "--out", str(tmp_path)],
-                         capture_output=True, text=True, timeout=120)
+                          "--start", "10", "--step", "40", "--elevation", "25", "--out", str(tmp_path)] +
+                         (["--pageable"] if hand_off == "pageable" else []), capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stderr
     vol, _ = oracle.normalize(oracle.phantom(n, np.uint16))
     lut = np.zeros((256, 4), np.float32)

@@ -28,7 +28,7 @@ ABI_SYMBOLS = (
     "vr_phantom_generate_device", "vr_phantom_generate_box_device",
     "vr_brick_grid", "vr_subvolume_voxels", "vr_upload_subvolume_device", "vr_render_partial",
     "vr_composite_pair", "vr_composite_ordered", "vr_decide_partials", "vr_chain_stage",
-    "vr_store_chain", "vr_occupied_brick_counts", "vr_render_static", "vr_static_max_pixels",
+    "vr_store_chain", "vr_occupied_brick_counts", "vr_render_static", "vr_static_max_pixels", "vr_render_mapped", "vr_map_frame", "vr_unmap_frame",
 )
 PARTIAL_FLOATS = 5   # floats per pixel of a sort-last partial result: F0, F1, F2, Tr, S
 
@@ -102,6 +102,9 @@ def lib():
     L.vr_render_bands.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.POINTER(Stats)]
     L.vr_render_static.argtypes = [vp, C.c_int, C.c_int, vp]
     L.vr_static_max_pixels.argtypes = []
+    L.vr_render_mapped.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.vr_map_frame.argtypes = [vp, C.c_int, C.POINTER(C.POINTER(C.c_uint8))]
+    L.vr_unmap_frame.argtypes = [vp, C.c_int]
     L.vr_set_pipeline.argtypes = [vp, C.c_int]
     L.vr_wait_frame.argtypes = [vp, vp]
     L.vr_band_rows.argtypes = [C.c_int, C.c_int, C.c_int]
@@ -380,6 +383,24 @@ class VolumeRenderer:
         """vr_render_static: a fast frame into device memory at `ptr` that allocates nothing (scratch from the
         library's static device array; frames up to static_max_pixels())."""
         self._check(lib().vr_render_static(self._h, width, height, ptr))
+
+    # --- frames for a consumer on the host (the reference's copyImage hand-off, main.cpp:903-909) ---
+    def render_mapped(self, width, height):
+        """Renders a frame into one of the context's three slots and enqueues its copy into page-locked host
+        memory beside the next frame's march; returns the slot for map_frame."""
+        frame_id = C.c_int()
+        self._check(lib().vr_render_mapped(self._h, width, height, C.byref(frame_id)))
+        return frame_id.value
+
+    def map_frame(self, frame_id, width, height):
+        """Waits for the frame of that slot and returns a (height, width, 4) uint8 VIEW of the library's
+        page-locked memory, valid until unmap_frame(frame_id)."""
+        p = C.POINTER(C.c_uint8)()
+        self._check(lib().vr_map_frame(self._h, frame_id, C.byref(p)))
+        return np.ctypeslib.as_array(p, shape=(height, width, 4))
+
+    def unmap_frame(self, frame_id):
+        self._check(lib().vr_unmap_frame(self._h, frame_id))
 
     # --- sort-last: one box of the volume's brick grid per context (no reference counterpart) ---
     def phantom_generate_box_device(self, ptr, dtype_bytes, n, lo, hi, seed=0x5EED1234):

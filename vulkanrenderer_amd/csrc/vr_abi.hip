@@ -167,6 +167,19 @@ struct vr_ctx {
     size_t order_cap = 0;               // tiles per list
     bool order_valid[kSets] = {false, false, false};
     int order_key[kSets][7] = {{0}, {0}, {0}};   // the rectangle, split and tile count the lists of a set are for
+    // Frames for a consumer on the host (vr_render_mapped / vr_map_frame): three slots in turn, each a device
+    // image and a page-locked host image of the same size; the copy of frame n runs on a stream of its own
+    // under the march of frame n + 1.
+    struct MappedSlot {
+        uint8_t *dev = nullptr, *host = nullptr;
+        size_t cap = 0;               // bytes both images hold
+        hipEvent_t copied = nullptr;  // recorded behind the slot's copy
+        bool pending = false, mapped = false;
+    };
+    static constexpr int kMapped = 3;
+    MappedSlot mapped[kMapped];
+    hipStream_t copy_stream = nullptr;
+    uint64_t mapped_index = 0;
     // test hook (VR_TEST_FAIL_ALLOC=n at vr_create): the n-th device allocation of a volume upload
     // fails, so that the error path of the upload can be exercised without exhausting the GPU
     int fail_alloc_in = 0;
@@ -765,6 +778,13 @@ int vr_destroy(vr_ctx *ctx)
         if (ctx->ranges_free[k]) (void)hipEventDestroy(ctx->ranges_free[k]);
     }
     if (ctx->prep_stream) (void)hipStreamDestroy(ctx->prep_stream);
+    if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+    for (vr_ctx::MappedSlot &m : ctx->mapped) {
+        if (m.dev) (void)dev_free(m.dev);
+        if (m.host) (void)hipHostFree(m.host);
+        if (m.copied) (void)hipEventDestroy(m.copied);
+    }
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     for (int k = 0; k < vr_ctx::kSets; k++) {
         if (ctx->main_done[k]) (void)hipEventDestroy(ctx->main_done[k]);
         if (ctx->tail_done[k]) (void)hipEventDestroy(ctx->tail_done[k]);
@@ -1430,6 +1450,68 @@ int vr_render_static(vr_ctx *ctx, int width, int height, uint8_t *d_out)
 }
 
 int vr_static_max_pixels(void) { return (int)static_scratch::kMaxPixels; }
+
+int vr_render_mapped(vr_ctx *ctx, int width, int height, int *frame_id)
+{
+    if (!ctx || !frame_id) return fail(ctx, VR_ERR_ARG, "null argument");
+    if (width < 2 || height < 2 || width > 65536 || height > 65536) return fail(ctx, VR_ERR_ARG, "image size out of range");
+    if (int rc = bind(ctx)) return rc;
+    const int id = (int)(ctx->mapped_index % (uint64_t)vr_ctx::kMapped);
+    vr_ctx::MappedSlot &m = ctx->mapped[id];
+    if (m.mapped) return fail(ctx, VR_ERR_STATE, "the oldest of the three mapped frames has not been given back (vr_unmap_frame)");
+    if (!ctx->copy_stream) VR_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    if (!m.copied) VR_HIP(ctx, hipEventCreateWithFlags(&m.copied, hipEventDisableTiming));
+    const size_t bytes = (size_t)width * (size_t)height * 4;
+    if (bytes > m.cap) {
+        if (m.pending) VR_HIP(ctx, hipEventSynchronize(m.copied));
+        m.pending = false;
+        if (m.dev) (void)dev_free(m.dev);
+        if (m.host) (void)hipHostFree(m.host);
+        m.dev = m.host = nullptr;
+        m.cap = 0;
+        VR_HIP(ctx, dev_alloc(&m.dev, bytes));
+        hipError_t e = hipHostMalloc((void **)&m.host, bytes, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            (void)dev_free(m.dev);
+            m.dev = nullptr;
+            return fail(ctx, VR_ERR_HIP, std::string("hipHostMalloc of the frame's page-locked image: ") + hipGetErrorString(e));
+        }
+        m.cap = bytes;
+    }
+    // the copy that last read this slot's device image comes before the frame that overwrites it
+    if (m.pending) VR_HIP(ctx, hipStreamWaitEvent(ctx->stream, m.copied, 0));
+    if (int rc = render_impl(ctx, width, height, 0, 0, width, height, 0, 1, m.dev, 1, nullptr)) return rc;
+    // the copy waits for the frame on a stream of its own, so that the next frame's march need not wait for it
+    if (int rc = vr_wait_frame(ctx, ctx->copy_stream)) return rc;
+    VR_HIP(ctx, hipMemcpyAsync(m.host, m.dev, bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
+    VR_HIP(ctx, hipEventRecord(m.copied, ctx->copy_stream));
+    m.pending = true;
+    ctx->mapped_index++;
+    *frame_id = id;
+    return VR_OK;
+}
+
+int vr_map_frame(vr_ctx *ctx, int frame_id, const uint8_t **pixels)
+{
+    if (!ctx || !pixels) return fail(ctx, VR_ERR_ARG, "null argument");
+    if (frame_id < 0 || frame_id >= vr_ctx::kMapped) return fail(ctx, VR_ERR_ARG, "no such frame");
+    vr_ctx::MappedSlot &m = ctx->mapped[frame_id];
+    if (!m.pending) return fail(ctx, VR_ERR_STATE, "no frame has been rendered into this slot");
+    if (int rc = bind(ctx)) return rc;
+    VR_HIP(ctx, hipEventSynchronize(m.copied));
+    m.mapped = true;
+    *pixels = m.host;
+    return VR_OK;
+}
+
+int vr_unmap_frame(vr_ctx *ctx, int frame_id)
+{
+    if (!ctx) return VR_ERR_ARG;
+    if (frame_id < 0 || frame_id >= vr_ctx::kMapped) return fail(ctx, VR_ERR_ARG, "no such frame");
+    ctx->mapped[frame_id].mapped = false;
+    return VR_OK;
+}
 
 int vr_render_bands(vr_ctx *ctx, int width, int height, int part, int parts, uint8_t *out, int out_is_device, vr_stats *stats)
 {
