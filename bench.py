@@ -145,6 +145,10 @@ def parse_args(argv=None):
                     help="hand the control graphs to the library in front of every frame, as the reference's renderCommands does "
                          "(main.cpp:800-804): the same graphs (default: the reference's loop with an idle editor), graphs whose "
                          "opacity values move, graphs whose transparent range moves; off: table set once in the set-up")
+    ap.add_argument("--exchange", choices=("python", "cabi"), default="python",
+                    help="who drives the multi-GPU exchange of a frame: vulkanrenderer_amd/sortfirst.py and sortlast.py over "
+                         "torch.distributed, or libvr_mg.so (include/vr_mg.h), the same sequence behind the C ABI over an RCCL "
+                         "communicator of its own; with one GPU the latter still issues every transfer (to itself)")
     ap.add_argument("--stats-frames", type=int, default=12, help="frames measured with counters for the roofline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-tune", action="store_true",
@@ -202,6 +206,8 @@ class Setup:
         self.camera = fixed_camera if cfg["camera"] == "fixed" else orbit_camera
 
     def fence(self, ctx):
+        if getattr(self, "layer", None) is not None:
+            self.layer.synchronize()     # libvr_mg.so's gather runs on a stream of its own
         ctx.synchronize()
         self.torch.cuda.synchronize()
         if self.world > 1:
@@ -228,6 +234,20 @@ class Setup:
         if self.overridden:
             text += " [not the named configuration: %s overridden]" % ", ".join(self.overridden)
         return text
+
+
+def multi_gpu_layer(su, ctx):
+    """This rank's end of libvr_mg.so's communicator: rank 0 makes the RCCL unique id, torch.distributed hands it round."""
+    from vulkanrenderer_amd import multigpu as mgl
+    torch = su.torch
+    if su.world > 1 and su.backend != "nccl":
+        raise SystemExit("--exchange cabi needs one GPU per rank (RCCL refuses two ranks on one device)")
+    uid = mgl.unique_id() if su.rank == 0 else bytes(mgl.UNIQUE_ID_BYTES)
+    if su.world > 1:
+        t = torch.tensor(list(uid), dtype=torch.uint8, device=su.device)
+        su.dist.broadcast(t, 0)
+        uid = bytes(t.cpu().tolist())
+    return mgl, mgl.MultiGpu(ctx, uid, su.rank, su.world)
 
 
 def counters_of_profiles(key):
@@ -285,11 +305,22 @@ def run_sort_first(args, su):
 
     base_graphs = TRANSLUCENT_GRAPHS if args.table == "translucent" else TF_GRAPHS
     tf_kind = [args.tf_every_frame]
+    layer = None
+    if args.exchange == "cabi":
+        _, layer = multi_gpu_layer(su, ctx)
+        if targets is None and rank == 0:
+            targets = [sf.frame, torch.zeros_like(sf.frame), torch.zeros_like(sf.frame)]
+            torch.cuda.synchronize()
+
+    su.layer = layer
 
     def frame(step):
         if tf_kind[0] != "off":   # the reference's frame: table, uniforms, dispatch (main.cpp:800-828)
             ctx.update_transfer_function(base_graphs if tf_kind[0] == "same" else frame_graphs(step, tf_kind[0]))
         ctx.set_camera(*su.camera(step))
+        if layer is not None:     # bands, gather into the frame's rows and the waits between them behind one call
+            layer.render_sort_first(w, h, targets[step % 3].data_ptr() if rank == 0 else 0)
+            return
         if world == 1:
             ctx.render_bands(w, h, 0, 1, ptr=targets[step % 3].data_ptr())
             return
@@ -452,6 +483,7 @@ def run_sort_first(args, su):
                 "volume": [n, n, n], "image": [w, h], "samples_per_ray": samples, "mode": args.mode,
                 "parallelism": "sort-first x%d (16-row bands, replicated volume, RCCL gather)" % world if world > 1 else "single GPU",
                 "frames_in_flight": 2,
+                "exchange": "libvr_mg.so (C ABI, own RCCL communicator)" if layer is not None else "vulkanrenderer_amd/sortfirst.py (torch.distributed)",
                 "tf_every_frame": args.tf_every_frame,
                 "shading": bool(args.shading),
                 "lane_budget": lane_budget,
@@ -459,6 +491,9 @@ def run_sort_first(args, su):
             },
             "roofline": roofline,
         }
+    if layer is not None:
+        su.layer = None
+        layer.close()
     ctx.close()
     return line
 
@@ -498,8 +533,20 @@ def run_sort_last(args, su):
     engine = sl.HipEngine(ctx, w, h)
     fr = sl.SortLastFrame(engine, w, h, rank, world, device, grid=grid, schedule=schedule, host_staging=su.backend != "nccl")
 
+    layer, out_frame = None, None
+    if args.exchange == "cabi":
+        mgl, layer = multi_gpu_layer(su, ctx)
+        layer.set_box_grid(grid)
+        su.layer = layer
+        out_frame = torch.zeros((h, w, 4), dtype=torch.uint8, device=device) if rank == 0 else None
+        torch.cuda.synchronize()
+        cabi_schedule = mgl.BINARY_SWAP if schedule == "binary_swap" else mgl.DIRECT_SEND
+
     def frame(step, mark=None):
         ctx.set_camera(*su.camera(step))
+        if layer is not None and mark is None:    # the timed frames; the per-stage pass below uses the Python driver's marks
+            fr.remarched = layer.render_sort_last(w, h, cabi_schedule, out_frame.data_ptr() if rank == 0 else 0)
+            return out_frame
         return fr.render(mark=mark)
 
     for i in range(args.warmup):
@@ -570,6 +617,7 @@ def run_sort_last(args, su):
                 "volume": [n, n, n], "image": [w, h], "samples_per_ray": samples,
                 "parallelism": "sort-last x%d (boxes of bricks %dx%dx%d, %s over RCCL, byte-exact re-march of undecided pixels)" % (world, grid[0], grid[1], grid[2], schedule),
                 "bricks_of_rank0": [list(lo), list(hi)], "balance": args.balance if world > 1 else "one box", "lane_budget_rank0": lane_budget,
+                "exchange": "libvr_mg.so (C ABI, own RCCL communicator)" if layer is not None else "vulkanrenderer_amd/sortlast.py (torch.distributed)",
                 "setup_s": round(t_setup, 2),
             },
             "stages": stages,
@@ -583,6 +631,9 @@ def run_sort_last(args, su):
                 "kernel_ms_avg": float(np.mean(march)),
             },
         }
+    if layer is not None:
+        su.layer = None
+        layer.close()
     ctx.close()
     return line
 

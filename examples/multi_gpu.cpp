@@ -126,7 +126,7 @@ int main(int argc, char **argv)
     VR(whole, vr_render(whole, width, height, single.data(), 0, nullptr));     // what one GPU renders
 
     MG(first, vrmg_render_sort_first(first, width, height, d_a));
-    VR(whole, vr_synchronize(whole));
+    MG(first, vrmg_synchronize(first));       // the gather runs on the object's own stream
     int bad = 0;
     if (rank == 0) {
         if (hipMemcpy(got.data(), d_a, frame_bytes, hipMemcpyDeviceToHost) != hipSuccess) die("hipMemcpy", "frame");
@@ -160,7 +160,7 @@ int main(int argc, char **argv)
     for (int schedule : {VRMG_DIRECT_SEND, VRMG_BINARY_SWAP}) {
         uint64_t remarched = 0;
         MG(last, vrmg_render_sort_last(last, width, height, schedule, d_b, &remarched));
-        VR(part, vr_synchronize(part));
+        MG(last, vrmg_synchronize(last));
         if (rank == 0) {
             if (hipMemcpy(got.data(), d_b, frame_bytes, hipMemcpyDeviceToHost) != hipSuccess) die("hipMemcpy", "frame");
             const bool same = std::memcmp(got.data(), single.data(), frame_bytes) == 0;

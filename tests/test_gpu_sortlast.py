@@ -336,8 +336,27 @@ def test_multi_gpu_layer_behind_the_c_abi(vr, torch, oracle):
                 frame.zero_()
                 torch.cuda.synchronize()
                 m.render_sort_first(w, h, frame.data_ptr())
-                c.synchronize()
+                m.synchronize()
                 assert np.array_equal(frame.cpu().numpy(), want), pipeline
+                # five frames of an orbit back to back into three buffers (the gathers run beside the next marches,
+                # band buffers in turn); the host waits once, torch's stream through vrmg_wait_frame
+                cams = [(cam[0] + 0.2 * k, cam[1] + 0.05 * k) for k in range(5)]
+                singles = []
+                for k in (2, 3, 4):
+                    c.set_camera(*cams[k])
+                    singles.append(c.render(w, h))
+                bufs = [torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda") for _ in range(3)]
+                torch.cuda.synchronize()
+                for k in range(5):
+                    c.set_camera(*cams[k])
+                    m.render_sort_first(w, h, bufs[k % 3].data_ptr())
+                m.wait_frame(torch.cuda.current_stream().cuda_stream)
+                last = bufs[4 % 3].clone()          # on torch's stream, which now follows the last gather
+                m.synchronize()
+                torch.cuda.synchronize()
+                assert np.array_equal(last.cpu().numpy(), singles[2]), pipeline
+                assert np.array_equal(bufs[2 % 3].cpu().numpy(), singles[0]) and np.array_equal(bufs[3 % 3].cpu().numpy(), singles[1]), pipeline
+                c.set_camera(*cam)
             with pytest.raises(vr.VrError):
                 m.render_sort_last(w, h, mg.DIRECT_SEND, frame.data_ptr())       # no box grid yet
     with vr.VolumeRenderer(0) as c:
@@ -353,9 +372,18 @@ def test_multi_gpu_layer_behind_the_c_abi(vr, torch, oracle):
                 frame.zero_()
                 torch.cuda.synchronize()
                 remarched = m.render_sort_last(w, h, schedule, frame.data_ptr())
-                c.synchronize()
+                m.synchronize()
                 assert np.array_equal(frame.cpu().numpy(), want), schedule
                 assert 0 < remarched < 0.05 * w * h
+            # a larger frame after a smaller one: the buffers grow (and the ranks agree on it) in the middle of a run
+            w2, h2 = 333, 251
+            want2 = whole_frame(vr, vox, cam, w2, h2, samples)
+            big = torch.zeros((h2, w2, 4), dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            for schedule in (mg.BINARY_SWAP, mg.DIRECT_SEND):
+                m.render_sort_last(w2, h2, schedule, big.data_ptr())
+                m.synchronize()
+                assert np.array_equal(big.cpu().numpy(), want2), schedule
 
 
 def test_multi_gpu_example_program(tmp_path):

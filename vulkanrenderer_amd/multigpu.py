@@ -14,7 +14,19 @@ LIB_PATH = os.path.join(_HERE, "libvr_mg.so")
 UNIQUE_ID_BYTES = 128
 DIRECT_SEND, BINARY_SWAP = 0, 1
 MG_SYMBOLS = ("vrmg_get_unique_id", "vrmg_create", "vrmg_create_from_comm", "vrmg_destroy", "vrmg_last_error",
-              "vrmg_render_sort_first", "vrmg_set_box_grid", "vrmg_render_sort_last")
+              "vrmg_render_sort_first", "vrmg_wait_frame", "vrmg_synchronize", "vrmg_set_box_grid", "vrmg_render_sort_last",
+              "vrmg_plan_sort_last")
+MAX_ROUNDS = 16
+
+
+class Round(C.Structure):
+    _fields_ = [("partner", C.c_int), ("axis", C.c_int), ("mine_is_low", C.c_int), ("out_buffer", C.c_int),
+                ("keep_offset", C.c_uint64), ("send_offset", C.c_uint64), ("count", C.c_uint64), ("first_pixel", C.c_uint64)]
+
+
+class Plan(C.Structure):
+    _fields_ = [("pixels", C.c_uint64), ("padded", C.c_uint64), ("span", C.c_uint64), ("first", C.c_uint64),
+                ("box", C.c_int * 3), ("rounds", C.c_int), ("round", Round * MAX_ROUNDS)]
 
 _lib = None
 
@@ -35,6 +47,9 @@ def lib():
     L.vrmg_last_error.argtypes = [vp]
     L.vrmg_last_error.restype = C.c_char_p
     L.vrmg_render_sort_first.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.vrmg_wait_frame.argtypes = [vp, vp]
+    L.vrmg_synchronize.argtypes = [vp]
+    L.vrmg_plan_sort_last.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.POINTER(Plan)]
     L.vrmg_set_box_grid.argtypes = [vp, C.POINTER(C.c_int)]
     L.vrmg_render_sort_last.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.POINTER(C.c_uint64)]
     for name in MG_SYMBOLS:
@@ -42,6 +57,15 @@ def lib():
             getattr(L, name).restype = C.c_int
     _lib = L
     return L
+
+
+def plan_sort_last(rank, world, grid, schedule, width, height):
+    """The schedule of a sort-last frame for one rank (pure host arithmetic, usable without a GPU): a Plan."""
+    plan = Plan()
+    rc = lib().vrmg_plan_sort_last(rank, world, _i3(grid), schedule, width, height, C.byref(plan))
+    if rc != 0:
+        raise VrError("vrmg_plan_sort_last failed with %d" % rc)
+    return plan
 
 
 def unique_id():
@@ -78,6 +102,13 @@ class MultiGpu:
 
     def render_sort_first(self, width, height, frame_ptr):
         self._check(lib().vrmg_render_sort_first(self._h, width, height, frame_ptr))
+
+    def wait_frame(self, stream_handle):
+        """Orders a stream (its hipStream_t as an integer; 0 = default stream) after the most recent frame."""
+        self._check(lib().vrmg_wait_frame(self._h, stream_handle))
+
+    def synchronize(self):
+        self._check(lib().vrmg_synchronize(self._h))
 
     def set_box_grid(self, grid):
         self._check(lib().vrmg_set_box_grid(self._h, _i3(grid)))
