@@ -34,8 +34,8 @@ extern "C" {
 /* Render strategies.  Both produce the frame the reference shader defines. */
 #define VR_MODE_REFERENCE_ORDER 0 /* back-to-front, every tap (VolumeRendering.comp:183-202) */
 #define VR_MODE_FAST 1            /* front-to-back, macrocell skipping, early termination; for a table under which
-                                     rays do not become opaque (more than a tenth of the pixels of a whole frame
-                                     undecided) the following frames take VR_MODE_REFERENCE_SKIP's path */
+                                     rays do not become opaque (more than one in a hundred of the pixels of a whole
+                                     frame undecided) the following frames take VR_MODE_REFERENCE_SKIP's path */
 #define VR_MODE_REFERENCE_SKIP 2  /* back-to-front, taps in exactly transparent bricks not fetched */
 
 typedef struct vr_ctx vr_ctx;

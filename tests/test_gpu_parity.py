@@ -331,6 +331,43 @@ def test_camera_inside_the_box(ctx, oracle, mode):
     assert want[..., :3].any()
 
 
+@pytest.mark.parametrize("case", ["apex_on_a_pixel", "nan_in_one_row", "infinite_translation"])
+def test_rays_that_are_not_numbers(ctx, oracle, case):
+    """Raw uniforms that make tap positions NaN: a camera whose apex is the world position of one of its own
+    pixels (direction 0 / 0), a NaN in the row of the matrix that gives world y (x and z stay finite, so the slab
+    test still finds hits), an infinite translation.  The shader's arithmetic turns such pixels black -- every tap
+    NaN, NaN stored as 0 -- or misses the box; the index clamp sends NaN to the border texel.  All modes must agree
+    with the checker, and the modes that skip and stop early must not take the border brick such taps index for
+    empty space that leaves the colour alone."""
+    w, h, samples = 64, 48, 80
+    vox = oracle.phantom(32, np.uint16)
+    ctx.upload_volume(vox)
+    ctx.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+    ctx.set_sampling(samples)
+    vp, m = oracle.camera(math.radians(30.0), math.radians(20.0), w, h)
+    loc, m = vp[4:8].copy(), m.copy()
+    if case == "apex_on_a_pixel":
+        x0, y0 = np.float32(23), np.float32(17)
+        for c in range(3):      # world position of pixel (23, 17) in the kernel's own operation order
+            loc[c] = m[c] * x0 + (m[4 + c] * y0 + m[12 + c])
+    elif case == "nan_in_one_row":
+        m[1] = np.float32("nan")
+    else:
+        m[12] = np.float32("inf")
+    ctx.set_camera_raw(loc, m)
+    vol, _ = oracle.normalize(vox)
+    lut = np.zeros((256, 4), np.float32)
+    oracle.lut_update(lut, cf.TF_GRAPHS)
+    want = oracle.render(vol, lut, loc, m, w, h, samples)
+    assert np.all(want[..., 3] == 255)
+    if case == "apex_on_a_pixel":
+        assert np.all(want[17, 23, :3] == 0)
+    for mode in (0, 2, 1):
+        ctx.set_mode(mode)
+        got = ctx.render(w, h)
+        assert np.array_equal(got, want), (case, mode, cf.frame_report(got, want))
+
+
 def test_device_output_pointer(ctx, oracle, torch):
     ctx.upload_volume(oracle.phantom(32, np.uint8))
     ctx.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
@@ -415,7 +452,8 @@ def test_translucent_table_fast(ctx, oracle):
 
 
 def test_fast_mode_gives_way_under_a_translucent_table(ctx, oracle):
-    """Low alpha everywhere: no ray becomes opaque, most pixels of the first fast frame end in the replay.
+    """Low alpha everywhere: no ray becomes opaque, and several in a hundred of the first fast frame's pixels end in
+    the replay (one in a thousand under a table that makes rays opaque).
     From the second frame on fast mode renders through the skipping reference-order march: same bytes, no
     more taps than that mode fetches.  A new table re-arms the fast path."""
     xs = (0.0, 60.0, 300.0, 483.0)
@@ -432,7 +470,7 @@ def test_fast_mode_gives_way_under_a_translucent_table(ctx, oracle):
     ctx.set_mode(1)
     first, st_first = ctx.render(w, h, stats=True)
     assert np.array_equal(first, ref)
-    assert st_first["replay_rays"] > 0.1 * w * h                    # the probe frame paid for the replay
+    assert st_first["replay_rays"] > w * h / 100                    # the probe frame paid for the replay
     second, st = ctx.render(w, h, stats=True)
     assert np.array_equal(second, ref)
     assert st["replay_rays"] == 0 and st["long_rays"] == 0 and sum(st["rays_by_lane_taps"]) == 0

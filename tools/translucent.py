@@ -29,7 +29,7 @@ torch.cuda.synchronize()
 for name, graphs in (("benchmark table", bench.TF_GRAPHS), ("translucent table", TRANSLUCENT)):
     ctx.update_transfer_function(graphs, reset_state=True)
     frames = {}
-    for mode in (2, 1):
+    for mode in ((0, 2, 1) if len(sys.argv) > 1 else (2, 1)):
         ctx.set_mode(mode)
         ms = []
         for k in range(6):
@@ -46,8 +46,8 @@ for name, graphs in (("benchmark table", bench.TF_GRAPHS), ("translucent table",
         ctx.synchronize()
         frames[mode] = out.cpu().numpy().copy()
         hit = max(1, st["rays_hit"])
-        print("%s, mode %d: %.3f ms/frame; taps/ray %.1f (nominal %d), handed over %.1f%%, replayed %.1f%%, replay taps %.1f M, wave taps %.1f M" % (
-            name, mode, float(np.mean(ms)), st["samples_evaluated"] / hit, bench.samples_for(n) + 2, 100.0 * st["long_rays"] / hit,
+        print("%s, mode %d: %.3f ms/frame; look-ups/ray %.1f, taps/ray %.1f (nominal %d), handed over %.1f%%, replayed %.1f%%, replay taps %.1f M, wave taps %.1f M" % (
+            name, mode, float(np.mean(ms)), st["cells_read"] / hit, st["samples_evaluated"] / hit, bench.samples_for(n) + 2, 100.0 * st["long_rays"] / hit,
             100.0 * st["replay_rays"] / hit, st["replay_samples"] / 1e6, st["long_samples"] / 1e6))
     print("   frames identical:", bool(np.array_equal(frames[1], frames[2])))
 ctx.close()

@@ -117,13 +117,18 @@ __global__ __launch_bounds__(256) void k_lut_derive(const float4 *__restrict__ l
     }
 }
 
-// Range of LDS-table entries a filtered intensity between lo and hi (normalised) can read,
-// widened by one entry on each side.
+// Range of LDS-table entries a tap can read whose eight corners lie between lo and hi (normalised).
+// The filter's three levels of fma(w, b - a, a) keep a tap's intensity inside [lo, hi] up to a rounding of
+// the difference and one of the result per level, under four units in the last place of hi in all, so the
+// range is taken from [lo - hi * 1e-6, hi + hi * 1e-6] with the look-up's own arithmetic (sample_tf), which is
+// monotone.  A constant neighbourhood filters to exactly its value and gets exactly the two entries that value
+// reads: air at 0 is then the border entry and entry 0, whatever the table does from entry 1 on.
 __device__ __forceinline__ void tf_entry_range(float lo, float hi, int &first, int &last)
 {
-    const float xl = floorf(lo * 256.0f - 0.5f), xh = floorf(hi * 256.0f - 0.5f);
-    first = safe_index(xl, 256) + 2 - 1;
-    last = safe_index(xh, 256) + 3 + 1;
+    const float slack = hi * 1e-6f;
+    const float xl = floorf((lo - slack) * 256.0f - 0.5f), xh = floorf((hi + slack) * 256.0f - 0.5f);
+    first = safe_index(xl, 256) + 2;
+    last = safe_index(xh, 256) + 3;
     first = first < 0 ? 0 : first;
     last = last > kLutLds - 1 ? kLutLds - 1 : last;
 }
@@ -728,6 +733,17 @@ __device__ __forceinline__ int block_span(const RayModel &m, int t, const Cell &
     return span_inside(gx, gy, gz, c.sx & ~1, c.sy & ~1, c.sz & ~1, 2.0f, m);
 }
 
+// The bet on material of the marches that skip (see k_march_fast): after a tap with alpha != 0 the next taps are
+// fetched without a look at the occupancy tables.
+#ifndef VR_MATERIAL_BET
+#define VR_MATERIAL_BET true
+#endif
+constexpr bool kMaterialBet = VR_MATERIAL_BET;
+#ifndef VR_CLEAR_RUN
+#define VR_CLEAR_RUN 12
+#endif
+constexpr int kClearRun = VR_CLEAR_RUN;   // transparent taps in a row that end the bet on material
+
 // ---- reference-order march ---------------------------------------------------------------------
 // Back to front over the samples + 2 taps exactly as the shader loops (VolumeRendering.comp:
 // 183-202), same blend expression, so the colour is bit-identical to it.  With SKIP, a tap that
@@ -752,26 +768,42 @@ __global__ __launch_bounds__(256) void k_march_exact(VolumeView vol, FrameParams
         const float step = (r.tmax - r.tmin) / (float)(uint32_t)last;
         const RayModel rm = ray_model(r, vol, step, 1.0f);
         int t = 0;
+        // SKIP: after a tap with alpha != 0 the following taps are fetched without asking the occupancy tables
+        // (any tap may be fetched: one in empty space has alpha exactly 0 and blends as the identity), until
+        // kClearRun transparent taps in a row end the bet.  Inside material -- all of a ray under a table of low
+        // alpha everywhere -- a tap then costs what it costs the plain march, not two table look-ups more.
+        bool material = false;
+        int clear_run = 0;
         while (t <= last) {
             if (SKIP && t > 0) {
                 if (t < rm.t_stop) t = rm.t_stop;      // nothing occupied before or beyond these taps
                 if (t > rm.t_first || t > last) break;
-                if (STATS) lookups++;
-                const int n = empty_span(vol, rm, t);
-                if (n > 0) {
-                    t += n;
-                    continue;
+                if (!material) {
+                    if (STATS) lookups++;
+                    const int n = empty_span(vol, rm, t);
+                    if (n > 0) {
+                        t += n;
+                        continue;
+                    }
                 }
             }
             const Tap p = tap_position(r, vol, step, t);
             const Cell c = tap_cell(p, vol);
             const uint32_t brick = brick_of(c, vol);
-            if (SKIP && t > 0 && (brick_empty(brick, vol) || micro_empty(vol.micro[brick], c))) {
+            if (SKIP && t > 0 && !material && (brick_empty(brick, vol) || micro_empty(vol.micro[brick], c))) {
                 t++;
                 continue;
             }
             const float inten = sample_volume<T>(c, brick, vol);
             float4 tf = sample_tf(s_lut, inten);
+            if (SKIP) {
+                if (tf.w != 0.0f) {
+                    material = kMaterialBet;
+                    clear_run = 0;
+                } else if (material && ++clear_run >= kClearRun) {
+                    material = false;
+                }
+            }
             if (t == 0) {
                 cr = tf.x; cg = tf.y; cb = tf.z;
             } else {
@@ -1071,14 +1103,6 @@ constexpr int kLaneBudget = VR_LANE_BUDGET;
 #define VR_DECIDE_EVERY 4
 #endif
 constexpr int kDecideEvery = VR_DECIDE_EVERY;   // a power of two
-#ifndef VR_MATERIAL_BET
-#define VR_MATERIAL_BET true
-#endif
-constexpr bool kMaterialBet = VR_MATERIAL_BET;
-#ifndef VR_CLEAR_RUN
-#define VR_CLEAR_RUN 12
-#endif
-constexpr int kClearRun = VR_CLEAR_RUN;   // transparent taps in a row that end the bet on material
 #ifndef VR_MODEL_CELLS
 #define VR_MODEL_CELLS false
 #endif
