@@ -441,6 +441,11 @@ def run_sort_first(args, su):
             "limited_by": pmc.get("limited_by", "vector ALU under lane divergence"),
             "valu_busy": pmc.get("valu_busy"),
             "lanes_active": pmc.get("lanes_active"),
+            # the roofline that binds this kernel: share of the chip's vector-ALU lane-cycles that do useful work
+            # (pipes busy x lanes active in an issued instruction), from the same counter passes
+            "roofline_valu": {"bound": "valu", "frac": pmc["valu_busy"] * pmc["lanes_active"], "valu_busy": pmc["valu_busy"],
+                              "lanes_active": pmc["lanes_active"], "wave_valu_insts_per_launch": pmc.get("valu_insts_per_launch"),
+                              "source": pmc.get("source")} if pmc.get("valu_busy") and pmc.get("lanes_active") else None,
             "l2_hit": pmc.get("l2_hit"),
             "algorithmic_bytes_per_launch": kernel_bytes,
             "kernel_ms_avg": kern_s * 1e3,

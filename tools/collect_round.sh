@@ -18,6 +18,16 @@ timeout -k 10 300 python3 tools/band_times.py > "$out/band_times.txt" 2>&1 || ex
 for p in 8; do bash tools/share_profile.sh $p > "$out/share_$p.txt" 2>&1 || exit 1; done
 bash tools/small_config_profile.sh > "$out/small_configs.txt" 2>&1 || exit 1
 timeout -k 10 200 python3 tools/frame_stats.py > "$out/frame_stats.txt" 2>&1 || exit 1
-timeout -k 10 200 python3 tools/translucent.py > "$out/translucent.txt" 2>&1 || exit 1
+timeout -k 10 200 python3 tools/translucent.py all > "$out/translucent.txt" 2>&1 || exit 1
+bash tools/dense_profile.sh "$tag" > "$out/dense_profile.txt" 2>&1 || exit 1
+INGEST_REPS=8 bash tools/ingest_profile.sh "$tag" 2048 > "$out/ingest_profile.txt" 2>&1 || exit 1
+timeout -k 10 100 python3 tools/ingest_time.py 256 512 1024 2048 > "$out/ingest_times.txt" 2>&1 || exit 1
+for e in cabi; do
+  timeout -k 10 300 python3 bench.py --exchange $e --steps 120 --no-cpu-baseline > "$out/bench_c4_$e.json" 2> "$out/bench_c4_$e.err" || exit 1
+  timeout -k 10 300 python3 bench.py --config c5 --exchange $e --steps 120 --no-cpu-baseline > "$out/bench_c5_$e.json" 2> "$out/bench_c5_$e.err" || exit 1
+done
+for m in "" "--in-flight 2" "--pageable"; do
+  timeout -k 10 200 ./examples/orbit --phantom 2048 --size 3840x2160 --frames 360 --samples 7094 --mode 1 $m >> "$out/orbit_hand_off.txt" 2>&1 || exit 1
+done
 for e in 2048 4096; do bash tools/sortlast_balance.sh $e "$out" > "$out/sortlast_balance_$e.txt" 2>&1 || exit 1; done
 echo done

@@ -19,6 +19,7 @@ ap.add_argument("--frames", type=int, default=4)
 ap.add_argument("--mode", type=int, default=1)
 ap.add_argument("--parts", type=int, default=1, help="render only sort-first part 0 of this many")
 ap.add_argument("--shading", action="store_true", help="gradient lighting on")
+ap.add_argument("--table", choices=("benchmark", "translucent"), default="benchmark")
 a = ap.parse_args()
 n = a.volume
 ctx = vr.VolumeRenderer(0)
@@ -28,7 +29,7 @@ ctx.phantom_generate_device(raw.data_ptr(), 2, n)
 ctx.upload_volume_device(raw.data_ptr(), 2, n, n, n)
 ctx.synchronize()
 del raw
-ctx.update_transfer_function(bench.TF_GRAPHS, reset_state=True)
+ctx.update_transfer_function(bench.TRANSLUCENT_GRAPHS if a.table == "translucent" else bench.TF_GRAPHS, reset_state=True)
 ctx.set_sampling(bench.samples_for(n))
 ctx.set_mode(a.mode)
 if a.shading:
