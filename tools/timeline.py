@@ -105,6 +105,13 @@ for lo, hi in ((0, 50), (50, 100), (100, 200), (200, 400), (400, 800), (800, 1e9
 
 # cycles by phase (shader clock, elapsed while the wave shares its SIMD with others)
 cyc = t[:, 4:8].astype(np.float64)
+word7 = t[:, 7].astype(np.uint64)
+cyc[:, 3] = (word7 & np.uint64(0xffffffff)).astype(np.float64)
+hist = np.stack([((word7 >> np.uint64(32 + 8 * k)) & np.uint64(0xff)).astype(np.float64) for k in range(4)], axis=1)
+total_rounds = rounds.sum()
+shares = [hist[:, k].sum() / total_rounds for k in range(4)]
+print("fetch rounds by lanes that fetch in them: 1..8 %.3f, 9..16 %.3f, 17..32 %.3f, 33..48 %.3f, 49..64 %.3f" % (
+    shares[0], shares[1], shares[2], shares[3], 1.0 - sum(shares)))
 tot = cyc[:, 3].sum()
 print("cycle share: setup %.3f skip-loop %.3f sample %.3f rest %.3f" % (
     cyc[:, 0].sum() / tot, cyc[:, 1].sum() / tot, cyc[:, 2].sum() / tot, 1 - cyc[:, :3].sum() / tot))

@@ -1181,6 +1181,7 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
     const unsigned long long diag_t0 = wall_clock64();
     unsigned int diag_model = 0, diag_exact = 0, diag_rounds = 0, diag_sampled = 0, diag_wave_passes = 0, diag_wave_passes0 = 0, diag_pyramid = 0;
     long long diag_c0 = clock64(), diag_setup = 0, diag_skip = 0, diag_sample = 0;
+    unsigned long long diag_hist = 0;
 #endif
     const Ray r = make_ray(fp, in_rect ? px : fp.x0, in_rect ? py : fp.y0);
     const bool fast_ok = dec.ok;
@@ -1387,6 +1388,10 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
 #ifdef VR_DIAG
         diag_rounds++;
         diag_sampled += (unsigned int)taps;
+        {   // fetch rounds by how many lanes fetch in them: 1..8, 9..16, 17..32, 33..48 (the rest: 49..64)
+            const int fetching = __popcll(__ballot(have));
+            diag_hist += fetching <= 8 ? 1ull : fetching <= 16 ? (1ull << 8) : fetching <= 32 ? (1ull << 16) : fetching <= 48 ? (1ull << 24) : 0ull;
+        }
 #endif
         if (have) {
             work++;
@@ -1524,7 +1529,7 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
         g_vr_timeline[wave_id * 8 + 4] = (unsigned long long)diag_setup;
         g_vr_timeline[wave_id * 8 + 5] = (unsigned long long)diag_skip;
         g_vr_timeline[wave_id * 8 + 6] = (unsigned long long)diag_sample;
-        g_vr_timeline[wave_id * 8 + 7] = (unsigned long long)(clock64() - diag_c0);
+        g_vr_timeline[wave_id * 8 + 7] = ((unsigned long long)(clock64() - diag_c0) & 0xffffffffull) | (diag_hist << 32);
         g_vr_timeline[wave_id * 8 + 0] = diag_t0;
         g_vr_timeline[wave_id * 8 + 1] = wall_clock64();
         (void)hw; (void)xcc;
