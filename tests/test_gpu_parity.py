@@ -155,6 +155,31 @@ def test_ingest_strips_and_layers(ctx, oracle, monkeypatch, tmp_path, layers):
     assert cf.same_bits(ctx.read_volume_normalized(), want)
 
 
+def test_second_volume_of_the_same_shape(ctx, oracle):
+    """A new volume with the brick grid and voxel type of the old one moves into the old one's buffers: nothing of
+    the old volume may survive -- voxels, maximum, macrocells, occupancy -- and a frame in fast mode is the
+    checker's frame of the new volume.  Then another shape, and another voxel type (new buffers)."""
+    rng = np.random.default_rng(3)
+    first = oracle.phantom(40, np.uint16)
+    second = (rng.integers(0, 30000, size=first.shape) * (rng.random(first.shape) < 0.3)).astype(np.uint16)
+    second[5:9, 5:9, 5:9] = 41234
+    ctx.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+    ctx.set_camera(*cf.CAMERAS["h30_v20"])
+    ctx.set_sampling(100)
+    lut = np.zeros((256, 4), np.float32)
+    oracle.lut_update(lut, cf.TF_GRAPHS)
+    vp, m = oracle.camera(*cf.CAMERAS["h30_v20"], 96, 80)
+    for vox in (first, second, first[:, :24], second.astype(np.uint8)):
+        ctx.upload_volume(vox)
+        want, mx = oracle.normalize(vox)
+        assert ctx.volume_info()["max_value"] == mx
+        assert cf.same_bits(ctx.read_volume_normalized(), want)
+        ref = oracle.render(want, lut, vp[4:8], m, 96, 80, 100)
+        for mode in (1, 2, 0):
+            ctx.set_mode(mode)
+            assert np.array_equal(ctx.render(96, 80), ref), (vox.shape, vox.dtype, mode)
+
+
 def test_normalisation_exact_for_every_u16_value(ctx, oracle):
     for mx in (65535, 63536, 5119, 3272, 257, 3):
         vox = (np.arange(65536, dtype=np.uint32) % (mx + 1)).astype(np.uint16).reshape(16, 64, 64)

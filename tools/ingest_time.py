@@ -1,8 +1,8 @@
 """Time of the volume upload's device work (re-tiling into bricks + macrocells + maximum), HIP events.
 
 python tools/ingest_time.py [edge ...]      (default 2048; dtype u16; INGEST_BE=1: big-endian input)
-Prints per edge: ms of vr_upload_volume_device on a device-resident phantom (best of 3 after one
-warm-up), the bytes it has to move (u16: 2 B read per voxel, 1472 B of voxels + 4 B of macrocell written per brick) and the rate.
+Prints per edge: ms of vr_upload_volume_device on a device-resident phantom (best of the uploads after the
+first, which allocates; the later ones find the buffers in place), the bytes it has to move (u16: 2 B read per voxel, 1472 B of voxels + 4 B of macrocell written per brick) and the rate.
 """
 import os
 import sys

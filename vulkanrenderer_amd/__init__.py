@@ -49,6 +49,21 @@ class Stats(C.Structure):
         return {k: (list(getattr(self, k)) if k.startswith("rays_by_") else getattr(self, k)) for k, _ in self._fields_}
 
 
+class PackedGraphs:
+    """Four control graphs (R,G,B,A) of (x, intensity) points as the C arrays vr_set_transfer_function takes."""
+
+    def __init__(self, graphs):
+        self._keep, self.ptrs, self.counts = [], (C.POINTER(CtrlPt) * 4)(), (C.c_int * 4)()
+        for c in range(4):
+            g = list(graphs[c]) if c < len(graphs) and graphs[c] is not None else []
+            arr = (CtrlPt * max(1, len(g)))()
+            for k, (x, i) in enumerate(g):
+                arr[k].x, arr[k].intensity = float(x), float(i)
+            self._keep.append(arr)
+            self.ptrs[c] = C.cast(arr, C.POINTER(CtrlPt))
+            self.counts[c] = len(g)
+
+
 class VrError(RuntimeError):
     pass
 
@@ -266,17 +281,10 @@ class VolumeRenderer:
 
     # --- transfer function (updateTransferFunction, main.cpp:643-686) ------------------------
     def update_transfer_function(self, graphs, reset_state=False):
-        """graphs: four sequences (R,G,B,A) of (x, intensity) control points."""
-        keep, ptrs, counts = [], (C.POINTER(CtrlPt) * 4)(), (C.c_int * 4)()
-        for c in range(4):
-            g = list(graphs[c]) if c < len(graphs) and graphs[c] is not None else []
-            arr = (CtrlPt * max(1, len(g)))()
-            for k, (x, i) in enumerate(g):
-                arr[k].x, arr[k].intensity = float(x), float(i)
-            keep.append(arr)
-            ptrs[c] = C.cast(arr, C.POINTER(CtrlPt))
-            counts[c] = len(g)
-        self._check(lib().vr_set_transfer_function(self._h, ptrs, counts, int(bool(reset_state))))
+        """graphs: four sequences (R,G,B,A) of (x, intensity) control points, or a PackedGraphs (the same graphs
+        handed over every frame need not be packed into C arrays every frame)."""
+        packed = graphs if isinstance(graphs, PackedGraphs) else PackedGraphs(graphs)
+        self._check(lib().vr_set_transfer_function(self._h, packed.ptrs, packed.counts, int(bool(reset_state))))
 
     def transfer_function(self):
         out = np.empty((256, 4), np.float32)

@@ -383,8 +383,13 @@ int ingest_device(vr_ctx *ctx, const T *d_raw, int nx, int ny, int nz, float max
     if (sub && ctx->shading) return fail(ctx, VR_ERR_STATE, "shading is on: a sub-volume's apron does not hold the neighbours the gradient reads");
     const size_t brick_count = (size_t)(hi[0] - lo[0]) * (size_t)(hi[1] - lo[1]) * (size_t)(hi[2] - lo[2]);
     if (brick_count >= (1ull << 31)) return fail(ctx, VR_ERR_ARG, "volume too large");
-    // From here on the old volume is gone.
-    release_volume(ctx);
+    // From here on the old volume is gone.  Its buffers are kept when the new volume has the same brick grid and
+    // voxel type (a time series, a re-upload): allocating and releasing 26 GB costs a hundred times what the pass
+    // over the voxels does.
+    const bool reuse = ctx->bricks && ctx->dtype == (int)sizeof(T) && ctx->brick_count == brick_count && ctx->nbx == hi[0] - lo[0] &&
+                       ctx->nby == hi[1] - lo[1] && ctx->nbz == hi[2] - lo[2] && ctx->fail_alloc_in == 0;
+    if (reuse) drain(ctx);   // frames still being finished read the old voxels
+    else release_volume(ctx);
     ctx->nx = nx; ctx->ny = ny; ctx->nz = nz;
     ctx->nbx = hi[0] - lo[0];
     ctx->nby = hi[1] - lo[1];
@@ -393,19 +398,22 @@ int ingest_device(vr_ctx *ctx, const T *d_raw, int nx, int ny, int nz, float max
     for (int k = 0; k < 3; k++) ctx->brick_lo[k] = lo[k];
     ctx->brick_count = brick_count;
     ctx->dtype = (int)sizeof(T);
-    hipError_t err = volume_alloc(ctx, &ctx->bricks, brick_count * vr::kBrickElems * sizeof(T));
-    if (err == hipSuccess) err = volume_alloc(ctx, &ctx->cells, brick_count * sizeof(uint32_t));
-    if (err == hipSuccess) err = volume_alloc(ctx, &ctx->touched, ((brick_count + 31) / 32) * sizeof(uint32_t));
-    for (int l = 0; l < vr::kLevels; l++) {
-        ctx->lx[l] = l == 0 ? ctx->nbx : (ctx->lx[l - 1] + 3) / 4;
-        ctx->ly[l] = l == 0 ? ctx->nby : (ctx->ly[l - 1] + 3) / 4;
-        ctx->lz[l] = l == 0 ? ctx->nbz : (ctx->lz[l - 1] + 3) / 4;
-        const size_t cubes = (size_t)ctx->lx[l] * ctx->ly[l] * ctx->lz[l];
-        if (err == hipSuccess) err = volume_alloc(ctx, &ctx->empty[l], ((cubes + 31) / 32) * sizeof(uint32_t));
+    hipError_t err = hipSuccess;
+    if (!reuse) {
+        err = volume_alloc(ctx, &ctx->bricks, brick_count * vr::kBrickElems * sizeof(T));
+        if (err == hipSuccess) err = volume_alloc(ctx, &ctx->cells, brick_count * sizeof(uint32_t));
+        if (err == hipSuccess) err = volume_alloc(ctx, &ctx->touched, ((brick_count + 31) / 32) * sizeof(uint32_t));
+        for (int l = 0; l < vr::kLevels; l++) {
+            ctx->lx[l] = l == 0 ? ctx->nbx : (ctx->lx[l - 1] + 3) / 4;
+            ctx->ly[l] = l == 0 ? ctx->nby : (ctx->ly[l - 1] + 3) / 4;
+            ctx->lz[l] = l == 0 ? ctx->nbz : (ctx->lz[l - 1] + 3) / 4;
+            const size_t cubes = (size_t)ctx->lx[l] * ctx->ly[l] * ctx->lz[l];
+            if (err == hipSuccess) err = volume_alloc(ctx, &ctx->empty[l], ((cubes + 31) / 32) * sizeof(uint32_t));
+        }
+        if (err == hipSuccess) err = volume_alloc(ctx, &ctx->micro, brick_count * sizeof(unsigned long long));
+        if (err == hipSuccess) err = volume_alloc(ctx, &ctx->skip, ((brick_count + 15) / 16) * sizeof(uint32_t));
+        if (err == hipSuccess) err = volume_alloc(ctx, &ctx->occ_list, brick_count * sizeof(uint32_t));
     }
-    if (err == hipSuccess) err = volume_alloc(ctx, &ctx->micro, brick_count * sizeof(unsigned long long));
-    if (err == hipSuccess) err = volume_alloc(ctx, &ctx->skip, ((brick_count + 15) / 16) * sizeof(uint32_t));
-    if (err == hipSuccess) err = volume_alloc(ctx, &ctx->occ_list, brick_count * sizeof(uint32_t));
     uint32_t data_max = 0;
     if (err == hipSuccess) err = hipMemsetAsync(ctx->d_data_max, 0, sizeof(uint32_t), ctx->stream);
     if (err == hipSuccess) {
