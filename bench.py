@@ -348,14 +348,13 @@ def run_sort_first(args, su):
     elapsed = su.max_over_ranks(time.perf_counter() - t0)
     kernel_ms = ctx.march_kernel_times(min(args.steps, 1024))
 
-    # the same loop with the table set once, and with graphs that change every frame (untimed extras, shorter runs)
+    # the same loop with the table set once, with the same graphs handed over, and with graphs that change every
+    # frame: short runs over the same views for all four, so that they compare (outside the timed region)
     tf_extras = None
     if world == 1 and args.table == "benchmark":
-        tf_extras = {args.tf_every_frame: elapsed / args.steps * 1e3}
         short = min(args.steps, 120)
+        per_kind = {}
         for kind in ("off", "same", "values", "threshold"):
-            if kind == args.tf_every_frame:
-                continue
             tf_kind[0] = kind
             for i in range(args.warmup):
                 frame(i)
@@ -364,11 +363,13 @@ def run_sort_first(args, su):
             for i in range(short):
                 frame(i)
             su.fence(ctx)
-            tf_extras[kind] = (time.perf_counter() - t1) / short * 1e3
+            per_kind[kind] = (time.perf_counter() - t1) / short * 1e3
         tf_kind[0] = args.tf_every_frame
         ctx.update_transfer_function(base_graphs, reset_state=True)
-        tf_extras = {"ms_per_step": tf_extras, "frames": {k: (args.steps if k == args.tf_every_frame else short) for k in tf_extras},
-                     "timed_region_uses": args.tf_every_frame}
+        tf_extras = {"ms_per_step": per_kind, "frames": short, "timed_region_uses": args.tf_every_frame,
+                     "note": "off: table set once in the set-up; same: unchanged control graphs handed to the library in front of every "
+                             "frame (the reference's loop with an idle editor); values / threshold: graphs whose opacity values / whose "
+                             "transparent range move every frame"}
 
     # latency of single frames (untimed pass, one frame at a time on one stream): the spread over the views
     latency = None
