@@ -386,6 +386,63 @@ def test_multi_gpu_layer_behind_the_c_abi(vr, torch, oracle):
                 assert np.array_equal(big.cpu().numpy(), want2), schedule
 
 
+def test_multi_gpu_layer_reports_failures(vr, torch, oracle, monkeypatch):
+    """An allocation that fails while a frame's buffers grow (sort-first bands, sort-last frame buffers, the
+    re-march's lists): the call reports it after the ranks' agreement, nothing is left half sized, and the
+    same frame goes through once memory is there.  One rank: the agreement is an all-reduce over itself."""
+    from vulkanrenderer_amd import multigpu as mg
+    from vulkanrenderer_amd import sortlast as sl
+    n, w, h, samples = 64, 200, 150, 160
+    cam = cf.CAMERAS["hm135_vm60"]
+    vox = oracle.phantom(n, np.uint16)
+    want = whole_frame(vr, vox, cam, w, h, samples)
+    frame = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+
+    def refused(nth, call):
+        monkeypatch.setenv("VRMG_TEST_FAIL_ALLOC", str(nth))
+        try:
+            with pytest.raises(vr.VrError) as info:
+                call()
+        finally:
+            monkeypatch.delenv("VRMG_TEST_FAIL_ALLOC")
+        return str(info.value)
+
+    with vr.VolumeRenderer(0) as c:
+        c.upload_volume(vox)
+        c.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+        c.set_sampling(samples)
+        c.set_camera(*cam)
+        c.set_mode(vr.MODE_FAST)
+        with mg.MultiGpu(c, mg.unique_id(), 0, 1) as m:
+            for nth in (2, 1):                                   # the second of three band buffers, twice (the others have grown)
+                assert "memory" in refused(nth, lambda: m.render_sort_first(w, h, frame.data_ptr()))
+                m.synchronize()
+            m.render_sort_first(w, h, frame.data_ptr())
+            m.synchronize()
+            assert np.array_equal(frame.cpu().numpy(), want)
+    with vr.VolumeRenderer(0) as c:
+        sl.upload_box_of(c, vox, (1, 1, 1), (0, 0, 0), "cuda")
+        c.update_transfer_function(cf.TF_GRAPHS, reset_state=True)
+        c.set_sampling(samples)
+        c.set_camera(*cam)
+        with mg.MultiGpu(c, mg.unique_id(), 0, 1) as m:
+            m.set_box_grid((1, 1, 1))
+            # what has grown stays: direct send first fails on the partial image, then (with it in place) on the first
+            # buffer of the re-march; binary swap after it only needs its two work buffers
+            for schedule, nths in ((mg.DIRECT_SEND, (1, 2)), (mg.BINARY_SWAP, (2, 1))):
+                for nth in nths:
+                    msg = refused(nth, lambda: m.render_sort_last(w, h, schedule, frame.data_ptr()))
+                    print("schedule %d, allocation %d refused: %s" % (schedule, nth, msg))
+                    assert "memory" in msg, msg
+                    m.synchronize()
+                frame.zero_()
+                torch.cuda.synchronize()
+                assert m.render_sort_last(w, h, schedule, frame.data_ptr()) > 0
+                m.synchronize()
+                assert np.array_equal(frame.cpu().numpy(), want), schedule
+
+
 def test_multi_gpu_example_program(tmp_path):
     import subprocess
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "multi_gpu")

@@ -8,6 +8,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -19,6 +20,14 @@ constexpr int kPartialFloats = 5;   // F0, F1, F2, Tr, S per pixel (vr_render_pa
 constexpr int kBandRows = 16;       // rows of a sort-first band (vr_render_bands)
 constexpr int kTurns = 3;           // sort-first: band buffers and exchanges of this many frames in turn
 
+// Test hook: while VRMG_TEST_FAIL_ALLOC=n is in the environment, the n-th allocation of every frame call is refused.
+int g_allocations_this_call = 0;
+bool refused_by_test()
+{
+    const char *e = std::getenv("VRMG_TEST_FAIL_ALLOC");
+    return e && ++g_allocations_this_call == std::atoi(e);
+}
+
 struct Buffer {
     void *p = nullptr;
     size_t cap = 0;
@@ -28,6 +37,7 @@ struct Buffer {
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
+        if (refused_by_test()) return hipErrorOutOfMemory;
         const hipError_t e = hipMalloc(&p, bytes);
         if (e == hipSuccess) cap = bytes;
         else (void)hipGetLastError();
@@ -294,6 +304,7 @@ int vrmg_render_sort_first(vrmg *mg, int width, int height, uint8_t *d_frame)
     const size_t row_bytes = (size_t)width * 4u, stride = (size_t)rows0 * row_bytes;
     const int world = mg->world, rank = mg->rank;
     Status st{mg};
+    g_allocations_this_call = 0;
 
     // sizing first; when the band buffers have to grow, the ranks agree that all of them could
     if (stride > mg->agreed_bands) {
@@ -386,6 +397,7 @@ int vrmg_render_sort_last(vrmg *mg, int width, int height, int schedule, uint8_t
     if (hipSetDevice(mg->device) != hipSuccess) return fail(mg, VR_ERR_HIP, "hipSetDevice failed");
     hipStream_t s = mg->stream;
     Status st{mg};
+    g_allocations_this_call = 0;
 
     // every buffer of steps 1 to 3 and of the final gather, before the first collective
     if (padded > mg->agreed_padded[schedule]) {
