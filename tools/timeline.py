@@ -26,7 +26,8 @@ ctx.set_sampling(bench.samples_for(n))
 ctx.set_mode(1)
 out = torch.empty(w * h * 4, dtype=torch.uint8, device="cuda")
 waves = ((w + 7) // 8) * ((h + 15) // 16) * 2 + 8
-tl = torch.zeros(waves * 8, dtype=torch.int64, device="cuda")
+WORDS = 10   # kTimelineWords of the diagnostic build
+tl = torch.zeros(waves * WORDS, dtype=torch.int64, device="cuda")
 torch.cuda.synchronize()
 L = vr.lib()
 L.vr_diag_set_timeline.argtypes = [C.c_void_p, C.c_void_p]
@@ -39,7 +40,7 @@ ctx.set_camera(*bench.orbit_camera(30))
 ctx.render_device(w, h, out.data_ptr())
 ctx.synchronize()
 print("kernel ms", ctx.march_kernel_times(1))
-t = tl.cpu().numpy().reshape(-1, 8)
+t = tl.cpu().numpy().reshape(-1, WORDS)
 t = t[t[:, 0] != 0]
 t0, t1 = t[:, 0].astype(np.float64), t[:, 1].astype(np.float64)
 base = t0.min()
@@ -86,7 +87,7 @@ print("sum dur (wave-us)", dur.sum(), "-> avg resident waves", dur.sum() / t1.ma
 # the longest waves: where are they in the image
 order = np.argsort(-dur)[:10]
 tiles_x = (w + 7) // 8
-ids = np.nonzero(tl.cpu().numpy().reshape(-1, 8)[:, 0])[0]
+ids = np.nonzero(tl.cpu().numpy().reshape(-1, WORDS)[:, 0])[0]
 for k in order:
     wid = ids[k]
     print("wave", wid, "tile", wid % tiles_x, wid // tiles_x, "dur us %.1f start %.0f" % (dur[k], t0[k]),
@@ -121,3 +122,21 @@ print("busy waves (%.2f of all cycles): setup %.3f skip-loop %.3f sample %.3f; p
     totb / tot, cyc[b, 0].sum() / totb, cyc[b, 1].sum() / totb, cyc[b, 2].sum() / totb,
     cyc[b, 1].sum() / rounds[b].sum(), cyc[b, 2].sum() / rounds[b].sum()))
 print("idle waves: setup %.0f skip-loop %.0f total %.0f cycles per wave" % (cyc[~b, 0].mean(), cyc[~b, 1].mean(), cyc[~b, 3].mean()))
+
+# how often a WAVE ran each part of the lane march (what tools/valu_attribution.py multiplies the parts' instruction counts with)
+more = t[:, 8].astype(np.uint64)
+preps = (more & np.uint64(0xffff)).astype(np.float64)
+decides = ((more >> np.uint64(16)) & np.uint64(0xffff)).astype(np.float64)
+flags = (more >> np.uint64(32)).astype(np.int64)
+counts = {
+    "waves": int(len(t)), "waves_nothing_behind_tile": int(np.count_nonzero(flags & 1)), "skip_passes": float(wave_passes.sum()),
+    "rounds": float(rounds.sum()), "rounds_preparing_material_taps": float(preps.sum()), "rounds_with_decision_test": float(decides.sum()),
+    "waves_handing_over": int(np.count_nonzero(flags & 2)), "waves_with_back_tap": int(np.count_nonzero(flags & 4)),
+    "waves_queueing_replay": int(np.count_nonzero(flags & 8)),
+    "cycles": {"all": float(cyc[:, 3].sum()), "setup": float(t[:, 4].sum()),
+               "skip_loop": float(t[:, 5].sum()), "fetch_rounds_with_decision": float(t[:, 6].sum()), "decision_test": float(t[:, 9].sum())},
+}
+print("wave-level executions:", counts)
+import json  # noqa: E402
+os.makedirs("gpurun_out", exist_ok=True)
+json.dump(counts, open("gpurun_out/timeline_counts.json", "w"), indent=1)

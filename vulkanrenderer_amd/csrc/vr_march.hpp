@@ -18,7 +18,8 @@ namespace vr {
 #endif
 
 #ifdef VR_DIAG
-__device__ unsigned long long *g_vr_timeline = nullptr;
+__device__ unsigned long long *g_vr_timeline = nullptr;   // kTimelineWords per wave of the lane march (tools/timeline.py)
+constexpr int kTimelineWords = 10;
 #endif
 
 // ---- what the marches need to know about the current transfer function ----------------------
@@ -1182,6 +1183,8 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
     unsigned int diag_model = 0, diag_exact = 0, diag_rounds = 0, diag_sampled = 0, diag_wave_passes = 0, diag_wave_passes0 = 0, diag_pyramid = 0;
     long long diag_c0 = clock64(), diag_setup = 0, diag_skip = 0, diag_sample = 0;
     unsigned long long diag_hist = 0;
+    unsigned int diag_preps = 0, diag_decides = 0;   // rounds in which the wave prepared taps of lanes inside material / ran the decision test
+    long long diag_decide = 0;
 #endif
     const Ray r = make_ray(fp, in_rect ? px : fp.x0, in_rect ? py : fp.y0);
     const bool fast_ok = dec.ok;
@@ -1242,6 +1245,9 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
         uint32_t &brick = bricks[0];
         bool have = false;
         const bool active = marching && work < budget;
+#ifdef VR_DIAG
+        if (__ballot(material && active) != 0ull) diag_preps++;
+#endif
         if (material && active) {
             if (t < t_stop) {
                 marching = false;
@@ -1435,6 +1441,10 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
         }
         // 3. early termination, tested every few rounds for all lanes at once: the test costs about as
         //    much as half a tap and the whole wave pays for it whenever a single lane runs it
+#ifdef VR_DIAG
+        const long long diag_d0 = clock64();
+        if (__ballot(!PARTIAL && (round & (kDecideEvery - 1)) == kDecideEvery - 1 && fast_ok && marching && Tr < (double)dec.tr_gate) != 0ull) diag_decides++;
+#endif
         if (!PARTIAL && (round & (kDecideEvery - 1)) == kDecideEvery - 1 && fast_ok && marching && Tr < (double)dec.tr_gate) {
             if (try_decide(t + 1)) {     // taps t .. 0 are still to come
                 decided = true;
@@ -1447,10 +1457,18 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
             }
         }
 #ifdef VR_DIAG
+        diag_decide += clock64() - diag_d0;
         diag_sample += clock64() - diag_r1;
 #endif
     }
 
+#ifdef VR_DIAG
+    // what the wave does behind the loop: bit 0 no occupied brick behind the tile, 1 hands rays over, 2 fetches back taps
+    // (and runs the decision test on them), 3 queues rays for the replay
+    const unsigned long long diag_flags = (nothing ? 1ull : 0ull) | (__ballot(marching) != 0ull ? 2ull : 0ull) |
+                                          (__ballot(!marching && !PARTIAL && in_rect && r.hit && !gave_up && !decided) != 0ull ? 4ull : 0ull) |
+                                          (__ballot(gave_up) != 0ull ? 8ull : 0ull);
+#endif
     if (marching) {
         // out of budget with taps left: the next pass continues this ray
         LongRay e;
@@ -1526,15 +1544,17 @@ __device__ __forceinline__ void march_lanes(const VolumeView &vol, const FramePa
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         unsigned int xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        g_vr_timeline[wave_id * 8 + 4] = (unsigned long long)diag_setup;
-        g_vr_timeline[wave_id * 8 + 5] = (unsigned long long)diag_skip;
-        g_vr_timeline[wave_id * 8 + 6] = (unsigned long long)diag_sample;
-        g_vr_timeline[wave_id * 8 + 7] = ((unsigned long long)(clock64() - diag_c0) & 0xffffffffull) | (diag_hist << 32);
-        g_vr_timeline[wave_id * 8 + 0] = diag_t0;
-        g_vr_timeline[wave_id * 8 + 1] = wall_clock64();
+        g_vr_timeline[wave_id * kTimelineWords + 4] = (unsigned long long)diag_setup;
+        g_vr_timeline[wave_id * kTimelineWords + 5] = (unsigned long long)diag_skip;
+        g_vr_timeline[wave_id * kTimelineWords + 6] = (unsigned long long)diag_sample;
+        g_vr_timeline[wave_id * kTimelineWords + 7] = ((unsigned long long)(clock64() - diag_c0) & 0xffffffffull) | (diag_hist << 32);
+        g_vr_timeline[wave_id * kTimelineWords + 8] = (unsigned long long)diag_preps | ((unsigned long long)diag_decides << 16) | (diag_flags << 32);
+        g_vr_timeline[wave_id * kTimelineWords + 9] = (unsigned long long)diag_decide;
+        g_vr_timeline[wave_id * kTimelineWords + 0] = diag_t0;
+        g_vr_timeline[wave_id * kTimelineWords + 1] = wall_clock64();
         (void)hw; (void)xcc;
-        g_vr_timeline[wave_id * 8 + 2] = (unsigned long long)diag_wave_passes | ((unsigned long long)diag_wave_passes0 << 16) | ((unsigned long long)diag_lane_passes << 32) | ((unsigned long long)diag_pyramid << 48);
-        g_vr_timeline[wave_id * 8 + 3] = (unsigned long long)diag_rounds | ((unsigned long long)diag_model << 12) |
+        g_vr_timeline[wave_id * kTimelineWords + 2] = (unsigned long long)diag_wave_passes | ((unsigned long long)diag_wave_passes0 << 16) | ((unsigned long long)diag_lane_passes << 32) | ((unsigned long long)diag_pyramid << 48);
+        g_vr_timeline[wave_id * kTimelineWords + 3] = (unsigned long long)diag_rounds | ((unsigned long long)diag_model << 12) |
                                          ((unsigned long long)diag_exact << 24) | ((unsigned long long)diag_both << 36) |
                                          ((unsigned long long)diag_sum << 48);
     }
