@@ -420,7 +420,10 @@ def run_sort_first(args, su):
     line = None
     if rank == 0:
         kern_s = float(np.mean(kernel_ms)) / 1e3
-        fast = args.mode == "fast"
+        # fast mode gives way to the reference-order march with skipping under tables whose rays never go dark: the
+        # counting frames then show no brick touched by the lane march
+        gave_way = args.mode == "fast" and agg["main_bricks"] == 0 and agg["samples_evaluated"] > 0
+        fast = args.mode == "fast" and not gave_way
         brick_bytes = 512 * c["dtype"]
         # bytes the dominant kernel needs: the bricks IT touches (the tail kernels' bricks are not its), the
         # occupancy tables, the table and the frame it stores
@@ -428,13 +431,14 @@ def run_sort_first(args, su):
         kernel_bytes = brick_bytes * (agg["main_bricks"] if fast else agg["bricks_touched"]) + overhead
         achieved = kernel_bytes / kern_s / 1e9
         # PMC figures exist for whole-frame launches of configurations profiled with rocprofv3
-        pmc = counters_of_profiles("%d_%dx%d_%s%s" % (n, w, h, args.mode, "_shaded" if args.shading else "")) if world == 1 else None
+        pmc = counters_of_profiles("%d_%dx%d_%s%s%s" % (n, w, h, args.mode, "_shaded" if args.shading else "",
+                                                         "_translucent" if args.table == "translucent" else "")) if world == 1 else None
         if isinstance(pmc, (int, float)):
             pmc = {"traffic": pmc}
         pmc = pmc or {}
         roofline = {
             "bound": "hbm",
-            "kernel": "k_march_fast" if fast else "k_march_exact",
+            "kernel": "k_march_fast" if fast else "k_march_exact (reference order with skipping: fast mode gave way under this table)" if gave_way else "k_march_exact",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -442,7 +446,7 @@ def run_sort_first(args, su):
             "traffic": pmc.get("traffic"),
             "traffic_source": pmc.get("source", "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE passes of this workload)") if pmc.get("traffic") else None,
             # what the counters say limits the kernel: not the memory system
-            "limited_by": pmc.get("limited_by", "vector ALU under lane divergence"),
+            "limited_by": pmc.get("limited_by", "vector ALU under lane divergence" if fast else "vector ALU"),
             "valu_busy": pmc.get("valu_busy"),
             "lanes_active": pmc.get("lanes_active"),
             # the roofline that binds this kernel: share of the chip's vector-ALU lane-cycles that do useful work
@@ -450,6 +454,10 @@ def run_sort_first(args, su):
             "roofline_valu": {"bound": "valu", "frac": pmc["valu_busy"] * pmc["lanes_active"], "valu_busy": pmc["valu_busy"],
                               "lanes_active": pmc["lanes_active"], "wave_valu_insts_per_launch": pmc.get("valu_insts_per_launch"),
                               "source": pmc.get("source")} if pmc.get("valu_busy") and pmc.get("lanes_active") else None,
+            # the chip's lane-cycles (1024 SIMDs x 16 lanes at 2.4 GHz) over the kernel's time per tap: what a tap costs
+            # whatever fills the lanes; per tap the shader would execute and per tap this kernel fetched
+            "lane_cycles_per_nominal_tap": kern_s * 2.4e9 * 16384.0 * args.steps / max(1.0, float(nominal)),
+            "lane_cycles_per_fetched_tap": kern_s * 2.4e9 * 16384.0 / max(1.0, agg["samples_evaluated"] - agg["long_samples"] - agg["replay_samples"]),
             "l2_hit": pmc.get("l2_hit"),
             "algorithmic_bytes_per_launch": kernel_bytes,
             "kernel_ms_avg": kern_s * 1e3,

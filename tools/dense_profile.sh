@@ -18,12 +18,13 @@ for mode in 2 0; do
   pass sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY
   pass sq2 SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU SQ_INSTS_SMEM SQ_INSTS_BRANCH
   pass fetch FETCH_SIZE
+  pass write WRITE_SIZE
   pass tcc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum
   pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum
   cd "$root"
   echo "mode $mode" >> "$out/summary.txt"
   python3 tools/kernel_times.py "$out/kt$mode" | grep march >> "$out/summary.txt"
-  python3 tools/pmc_summary.py "$out/sq1$mode" "$out/sq2$mode" "$out/fetch$mode" "$out/tcc$mode" "$out/tcp$mode" | grep march_exact >> "$out/summary.txt"
+  python3 tools/pmc_summary.py "$out/sq1$mode" "$out/sq2$mode" "$out/fetch$mode" "$out/write$mode" "$out/tcc$mode" "$out/tcp$mode" | grep march_exact >> "$out/summary.txt"
   cd /tmp
 done
 cat "$out/summary.txt"

@@ -2,7 +2,9 @@
 quotes in its roofline object: HBM traffic per launch of the march kernel (FETCH_SIZE doubled, as gfx950
 tallies 128-byte reads at 64 bytes, plus WRITE_SIZE), L2 hit rate, lanes active and vector-ALU busy.
 
-  python tools/make_traffic_json.py gpurun_out/prof_r2 2048_3840x2160_fast profiles/r2"""
+  python tools/make_traffic_json.py gpurun_out/prof_r3 2048_3840x2160_fast profiles/r3
+  python tools/make_traffic_json.py gpurun_out/dense_r3 512_1920x1080_fast_translucent profiles/r3 k_march_exact 2
+      (the passes of tools/dense_profile.sh carry the mode as a suffix: sq12, fetch2, kt2 ...)"""
 import csv
 import glob
 import json
@@ -14,21 +16,26 @@ from pmc_summary import kernel_key, summarise  # noqa: E402
 
 prof, key, source = sys.argv[1], sys.argv[2], sys.argv[3]
 kernel = sys.argv[4] if len(sys.argv) > 4 else "k_march_fast"
+suffix = sys.argv[5] if len(sys.argv) > 5 else ""
 c = {}
 for name in ("sq1", "sq2", "fetch", "write", "tcc"):
-    c.update(summarise(os.path.join(prof, name)).get(kernel, {}))
+    if os.path.isdir(os.path.join(prof, name + suffix)):
+        c.update(summarise(os.path.join(prof, name + suffix)).get(kernel, {}))
 dur_ns = None
-for f in glob.glob(prof + "/**/*_kernel_stats.csv", recursive=True) + glob.glob(prof + "/bench_kernel_stats.csv"):
+stats = glob.glob(prof + "/kt" + suffix + "/**/*_kernel_stats.csv", recursive=True) if suffix else \
+    glob.glob(prof + "/**/*_kernel_stats.csv", recursive=True) + glob.glob(prof + "/bench_kernel_stats.csv")
+for f in stats:
     for r in csv.DictReader(open(f)):
-        if kernel_key(r["Name"]) == kernel and "false, false" in r["Name"]:
+        if kernel_key(r["Name"]) == kernel and (suffix or "false, false" in r["Name"]):
             dur_ns = float(r["AverageNs"])
 entry = {
-    "traffic": int(c["FETCH_SIZE"] * 1024 * 2 + c["WRITE_SIZE"] * 1024),
-    "source": "%s/pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes over tools/profile_frame.py, %s)" % (source, kernel),
+    "traffic": int(c["FETCH_SIZE"] * 1024 * 2 + c["WRITE_SIZE"] * 1024) if "WRITE_SIZE" in c else None,
+    "fetched": int(c["FETCH_SIZE"] * 1024 * 2),
+    "source": "%s (rocprofv3 --pmc passes over tools/profile_frame.py, %s; FETCH_SIZE x2 + WRITE_SIZE)" % (source, kernel),
     "l2_hit": c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]),
     "lanes_active": c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_INSTS_VALU"]),
     "valu_insts_per_launch": c["SQ_INSTS_VALU"],
-    "limited_by": "vector ALU under lane divergence",
+    "limited_by": "vector ALU under lane divergence" if kernel == "k_march_fast" else "vector ALU",
 }
 if dur_ns:
     # a wave64 vector instruction keeps its SIMD's pipe busy for 4 cycles; 1024 SIMDs at 2.4 GHz
