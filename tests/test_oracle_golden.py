@@ -78,6 +78,51 @@ def test_camera_default_pose(oracle):
         assert abs(np.linalg.norm(loc - np.array([0, 0, -0.5])) - 5.0) < 1e-5
 
 
+def test_camera_against_an_independent_rotation_library(oracle):
+    """The checker restates glm (rotate, translate, column-major products) by hand; here the same uniforms are
+    formed in float64 from the reference's statements (main.cpp:68-77, 182-202, 737-799) with scipy's axis-angle
+    rotation standing in for glm::rotate -- the right-handed rotation by `angle` about `axis`, which is what both
+    document -- and numpy's matrix product.  Agreement to float32 rounding says the hand-written restatement has
+    glm's conventions (sign of the angle, order of the products, columns versus rows) right."""
+    from scipy.spatial.transform import Rotation
+
+    def translate(v):
+        m = np.eye(4)
+        m[:3, 3] = v
+        return m
+
+    def rotate(angle, axis):
+        m = np.eye(4)
+        m[:3, :3] = Rotation.from_rotvec(angle * np.asarray(axis, np.float64)).as_matrix()
+        return m
+
+    start = np.eye(4)
+    start[:3, 2] = [0, 0, -1]                                   # side (1,0,0), up (0,1,0), forward (0,0,-1)  (:70-76)
+    pose = translate([0, -5.0, -0.5]) @ rotate(np.radians(90.0), [1, 0, 0]) @ start      # :193-196
+    centre = np.array([0, 0, -0.5])                                                       # :68
+    for hr, vr_ in cf.CAMERAS.values():
+        for (w, hgt) in ((512, 512), (1280, 720), (3840, 2160)):
+            turn = rotate(hr, [0, 0, 1]) @ rotate(vr_, [1, 0, 0])                         # :752-755
+            basis = pose.copy()
+            basis[:, 3] = [0, 0, 0, 1]
+            basis = turn @ basis
+            location = centre + (turn @ np.append(pose[:3, 3] - centre, 1.0))[:3]         # :756-757
+            frame = basis.copy()
+            frame[:, 3] = [0, 0, 0, 1]
+            to_world = (translate(location + 4.5 * basis[:3, 2]) @ frame @ translate([-0.5, 0.5, 0]) @
+                        np.diag([1.0, -1.0, 1.0, 1.0]) @ np.diag([1.0 / (w - 1.0), 1.0 / (hgt - 1.0), 1.0, 1.0]))   # :771-794
+            vp, m = oracle.camera(hr, vr_, w, hgt)
+            np.testing.assert_allclose(m.reshape(4, 4).T, to_world, atol=2e-6, rtol=0)
+            vp = vp.reshape(5, 4)
+            np.testing.assert_allclose(vp[0], [4.5, 0, 0, 0], atol=0)
+            np.testing.assert_allclose(vp[1], np.append(location, 1.0), atol=2e-6)
+            for k in range(3):
+                np.testing.assert_allclose(vp[2 + k], basis[:, k], atol=2e-6)
+            # a pixel's ray: the image plane is one unit wide and high, 4.5 from the apex, pixel (0, 0) top left
+            centre_pixel = to_world @ np.array([(w - 1) / 2.0, (hgt - 1) / 2.0, 0.0, 1.0])
+            np.testing.assert_allclose(centre_pixel[:3], location + 4.5 * basis[:3, 2], atol=1e-9)
+
+
 def test_frames_match_golden(oracle, golden):
     lut = golden["lut_four_points"]
     for dtype, n, tag in ((np.uint8, 32, "u8_32"), (np.uint16, 64, "u16_64")):
@@ -87,6 +132,62 @@ def test_frames_match_golden(oracle, golden):
             img = oracle.render(vol, lut, vp[4:8], m, 64, 64, 200)
             assert np.array_equal(img, golden["frame_%s_%s" % (tag, cname)]), (tag, cname)
             assert np.all(img[..., 3] == 255)
+
+
+def test_frames_against_a_library_sampler(oracle, golden):
+    """The shader's main() (VolumeRendering.comp:154-206, slab test :50-96) written a second time, vectorised over the
+    pixels in float64, with torch's grid_sample standing in for both texture() calls: linear filtering between texel
+    centres at (i + 0.5) / size with a zero border is what `align_corners=False, padding_mode="zeros"` computes and what
+    the sampler of main.cpp:365-382 asks Vulkan for.  The checker's scalar float32 loop has to agree with it up to
+    rounding: at most one unit in a byte, and nearly all bytes equal.  This does not pin the checker to the
+    reference (nothing can here); it pins its texel addressing, border, blend order and back tap to an
+    implementation that shares no code with it."""
+    import torch
+    import torch.nn.functional as F
+
+    lut = np.asarray(golden["lut_four_points"], np.float64).reshape(256, 4)
+    table = torch.from_numpy(lut.T.copy()).reshape(1, 4, 1, 256)
+    w = hgt = 64
+    samples = 200
+    for dtype, n in ((np.uint8, 32), (np.uint16, 64)):
+        vol, _ = oracle.normalize(oracle.phantom(n, dtype))
+        texture = torch.from_numpy(vol.astype(np.float64)).reshape(1, 1, n, n, n)
+        for cname, (hr, vr_) in cf.CAMERAS.items():
+            vp, m = oracle.camera(hr, vr_, w, hgt)
+            to_world = m.astype(np.float64).reshape(4, 4).T
+            eye = vp[4:7].astype(np.float64)
+            px, py = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(hgt, dtype=np.float64))
+            pixel = np.stack([px, py, np.zeros_like(px), np.ones_like(px)], -1) @ to_world.T
+            d = pixel[..., :3] - eye
+            d /= np.linalg.norm(d, axis=-1, keepdims=True)
+            lo, hi = np.array([-0.5, -0.5, -1.0]), np.array([0.5, 0.5, 0.0])
+            with np.errstate(divide="ignore", invalid="ignore"):
+                t1, t2 = (lo - eye) / d, (hi - eye) / d
+            tmin = np.minimum(t1, t2).max(-1)
+            tmax = np.maximum(t1, t2).min(-1)
+            hit = ~((tmin > tmax) | (tmax < 0))
+            step = (tmax - tmin) / (samples + 1)
+            colour = np.zeros((hgt, w, 3))
+            for t in range(samples + 2):
+                at = eye + (tmax - t * step)[..., None] * d
+                uvw = np.abs(at - np.array([-0.5, -0.5, 0.0]))
+                grid = torch.from_numpy(np.nan_to_num(2.0 * uvw - 1.0)).reshape(1, 1, hgt, w, 3)
+                value = F.grid_sample(texture, grid, mode="bilinear", padding_mode="zeros", align_corners=False).reshape(hgt, w)
+                at_table = torch.stack([2.0 * value - 1.0, torch.zeros_like(value)], -1).reshape(1, hgt, w, 2)
+                rgba = F.grid_sample(table, at_table, mode="bilinear", padding_mode="zeros", align_corners=False)[0].permute(1, 2, 0).numpy()
+                if t == 0:
+                    colour = rgba[..., :3].copy()
+                else:
+                    a = rgba[..., 3:4]
+                    colour = a * rgba[..., :3] + (1.0 - a) * colour
+            colour[~hit] = 0.0
+            want = np.rint(np.clip(colour, 0.0, 1.0) * 255.0).astype(np.int32)
+            got = oracle.render(vol, lut.astype(np.float32), vp[4:8], m, w, hgt, samples)[..., :3].astype(np.int32)
+            diff = np.abs(got - want)
+            print("%s %d^3: %.4f of the bytes equal, largest difference %d" % (cname, n, (diff == 0).mean(), diff.max()))
+            assert diff.max() <= 1, (cname, n, int(diff.max()))
+            assert (diff == 0).mean() >= 0.995, (cname, n, float((diff == 0).mean()))
+            assert hit.any() and not hit.all()
 
 
 def test_shaded_frames_match_golden(oracle, golden):
