@@ -816,15 +816,22 @@ def test_assemble_gathered_bands(ctx, oracle, torch):
         ctx.assemble_bands(w, h, 3, gathered.data_ptr(), 16, frame.data_ptr())
 
 
-@pytest.mark.parametrize("dtype,shape", [(np.uint8, (20, 33, 41)), (np.uint16, (17, 24, 30)), (np.uint16, (1, 1, 1))])
-def test_histogram_bit_exact(ctx, oracle, dtype, shape):
+@pytest.mark.parametrize("dtype,shape,top,given_max", [
+    (np.uint8, (20, 33, 41), 255, 0.0), (np.uint16, (17, 24, 30), 65535, 0.0), (np.uint16, (1, 1, 1), 65535, 0.0),
+    (np.uint16, (16, 16, 16), 65535, 0.0),        # the last brick of every axis holds two layers of voxels
+    (np.uint16, (6, 14, 130), 4000, 4095.0),      # 12-bit data with the maximum given; x ends exactly with a brick's apron
+    (np.uint8, (9, 70, 8), 7, 0.0),               # few values: most bins are empty, some values fall between bins
+])
+def test_histogram_bit_exact(ctx, oracle, dtype, shape, top, given_max):
     rng = np.random.default_rng(21)
-    top = 255 if dtype == np.uint8 else 65535
     vox = (rng.random(shape) ** 3 * top).astype(dtype)          # skewed: many small values, zeros included
-    vox[0, 0, 0] = max(1, int(vox[0, 0, 0]))                     # not all zero
-    ctx.upload_volume(vox)
-    want = oracle.histogram(oracle.normalize(vox)[0])
-    assert cf.same_bits(ctx.prepare_histogram_volume_data(), want)
+    vox[0, 0, 0] = top                                           # not all zero, and the value range is known
+    ctx.upload_volume(vox, given_max)
+    want = oracle.histogram(oracle.normalize(vox, given_max)[0])
+    got = ctx.prepare_histogram_volume_data()
+    assert cf.same_bits(got, want)
+    # the fullest bin is 1; a volume whose every voxel falls between two bins divides 0 by 0 as the reference would
+    assert got.max() == 1.0 or np.isnan(got).all()
 
 
 def test_histogram_of_the_phantom(ctx, oracle):

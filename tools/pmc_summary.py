@@ -30,5 +30,5 @@ def summarise(directory):
 if __name__ == "__main__":
     for d in sys.argv[1:]:
         for k, v in sorted(summarise(d).items()):
-            if any(w in k for w in ("march", "replay", "splat", "ingest", "classify")):
+            if any(w in k for w in ("march", "replay", "splat", "ingest", "classify", "hist")):
                 print(d.rstrip("/").split("/")[-1], k, "x%d" % v.pop("dispatches"), {c: "%.4g" % x for c, x in sorted(v.items())})

@@ -1008,40 +1008,53 @@ int vr_histogram(vr_ctx *ctx, float out[100])
     if (!ctx->bricks) return fail(ctx, VR_ERR_STATE, "no volume uploaded");
     if (ctx->sub) return fail(ctx, VR_ERR_STATE, "the context holds a sub-volume");
     if (int rc = bind(ctx)) return rc;
-    const size_t bins = 65536;
-    unsigned long long *d_hist = nullptr;
-    VR_HIP(ctx, dev_alloc(&d_hist, bins * sizeof(unsigned long long)));
-    hipError_t e = hipMemsetAsync(d_hist, 0, bins * sizeof(unsigned long long), ctx->stream);
-    const unsigned blocks = (unsigned)std::min<size_t>((ctx->brick_count * 64 + 255) / 256, 256 * 64);
-    if (ctx->dtype == VR_DTYPE_U8)
-        hipLaunchKernelGGL((vr::k_value_histogram<uint8_t>), dim3(blocks), dim3(256), 0, ctx->stream, view_of(ctx), d_hist);
-    else
-        hipLaunchKernelGGL((vr::k_value_histogram<uint16_t>), dim3(blocks), dim3(256), 0, ctx->stream, view_of(ctx), d_hist);
-    std::vector<unsigned long long> counts(bins);
-    if (e == hipSuccess) e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(counts.data(), d_hist, bins * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)dev_free(d_hist);
-    if (e != hipSuccess) return fail(ctx, VR_ERR_HIP, hipGetErrorString(e));
-
     // main.cpp:166-181 on the sorted normalised values, which are runs of float(v)/float(max), v ascending:
-    // lower_bound(x) = number of values < x, upper_bound(x) = number of values <= x
+    // lower_bound(x) = number of values < x, upper_bound(x) = number of values <= x, so bin i counts the raw
+    // values from the first v with !(float(v)/max < lo) up to the first v with hi < float(v)/max
     const float mx = ctx->max_value;
     const int top = (int)mx;
-    std::vector<unsigned long long> below(top + 2, 0);   // below[v] = voxels with a value < v
-    for (int v = 0; v <= top; v++) below[v + 1] = below[v] + counts[v];
+    const size_t values = ctx->dtype == VR_DTYPE_U8 ? 256 : 65536;
+    std::vector<uint8_t> bin_of(values, (uint8_t)vr::kHistBins);
     const float step = 1.0f / 100;                        // main.cpp:170
-    size_t count_max = 0;
-    for (int i = 0; i < 100; i++) {
+    for (int i = 0; i < vr::kHistBins; i++) {
         const float lo = step * (float)i;                  // main.cpp:174, float
         const double hi = (double)step * ((double)i + 0.9);   // main.cpp:175, double
-        int a = 0, b = top + 1;                            // first v with !(float(v)/max < lo)
+        int a = 0, b = top + 1;
         while (a < b) { const int m = (a + b) / 2; if ((float)m / mx < lo) a = m + 1; else b = m; }
-        const long long lower = (long long)below[a];
-        a = 0; b = top + 1;                                // first v with hi < float(v)/max
+        const int first = a;
+        a = 0; b = top + 1;
         while (a < b) { const int m = (a + b) / 2; if (!(hi < (double)((float)m / mx))) a = m + 1; else b = m; }
-        const long long upper = (long long)below[a];
-        const float c = (float)(upper - lower);            // main.cpp:176
+        for (int v = first; v < a && v < (int)values; v++) bin_of[(size_t)v] = (uint8_t)i;
+    }
+    uint8_t *d_bin = nullptr;
+    unsigned long long *d_hist = nullptr;
+    VR_HIP(ctx, dev_alloc(&d_bin, values));
+    if (dev_alloc(&d_hist, vr::kHistBins * sizeof(unsigned long long)) != hipSuccess) {
+        (void)dev_free(d_bin);
+        return fail(ctx, VR_ERR_HIP, "out of device memory for the histogram");
+    }
+    hipError_t e = hipMemsetAsync(d_hist, 0, vr::kHistBins * sizeof(unsigned long long), ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_bin, bin_of.data(), values, hipMemcpyHostToDevice, ctx->stream);
+    // one workgroup walks rows of bricks along x; two of them fit a compute unit's LDS
+    const unsigned blocks = (unsigned)std::min<size_t>((size_t)ctx->nby * ctx->nbz, 2 * 256);
+    if (e == hipSuccess) {
+        if (ctx->dtype == VR_DTYPE_U8)
+            hipLaunchKernelGGL((vr::k_bin_histogram<uint8_t>), dim3(blocks), dim3(vr::kHistThreads), 0, ctx->stream, view_of(ctx), d_bin, d_hist);
+        else
+            hipLaunchKernelGGL((vr::k_bin_histogram<uint16_t>), dim3(blocks), dim3(vr::kHistThreads), 0, ctx->stream, view_of(ctx), d_bin, d_hist);
+        e = hipGetLastError();
+    }
+    unsigned long long counts[vr::kHistBins] = {};
+    if (e == hipSuccess) e = hipMemcpyAsync(counts, d_hist, sizeof counts, hipMemcpyDeviceToHost, ctx->stream);
+    const hipError_t waited = hipStreamSynchronize(ctx->stream);   // also before bin_of and counts go out of scope
+    if (e == hipSuccess) e = waited;
+    (void)dev_free(d_hist);
+    (void)dev_free(d_bin);
+    if (e != hipSuccess) return fail(ctx, VR_ERR_HIP, hipGetErrorString(e));
+
+    size_t count_max = 0;
+    for (int i = 0; i < vr::kHistBins; i++) {
+        const float c = (float)(long long)counts[i];       // main.cpp:176
         out[i] = c;
         if (c > (float)count_max) count_max = (size_t)c;   // main.cpp:178
     }

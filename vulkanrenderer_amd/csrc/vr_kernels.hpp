@@ -698,44 +698,114 @@ __global__ __launch_bounds__(256) void k_read_normalized(VolumeView vol, float *
 }
 
 // ---- intensity histogram ---------------------------------------------------------------------
-// Counts of the raw voxel values (65536 bins), from which the host derives the reference's 100-bin
-// histogram (prepareHistogramVolumeData, main.cpp:166-181: float(v)/float(max) is monotone in v, so
-// its sorted-array bounds are sums of these counts).  One thread per x-row of 8 cells of a brick,
-// apron and padding left out so that every voxel counts once; equal neighbours are added together
-// and zeros, the background of most volumes, are summed per wave first.
+// The reference's 100 bins (prepareHistogramVolumeData, main.cpp:166-181) are ranges of the sorted normalised
+// values; float(v)/float(max) is monotone in v, so every bin is a range of raw values and the host hands the
+// kernel a table value -> bin (kHistBins for the values between two bins).  The kernel streams the bricks'
+// 8-element pieces that hold cells (the first 80 of a brick's 96; apron cells, which repeat a neighbour's voxels,
+// and cells outside the volume are masked out per piece from three small tables), looks every voxel's bin up in
+// LDS and counts it in one of kHistCopies LDS histograms (lanes that share a bin mostly do not share a counter;
+// the odd pitch spreads the copies over the banks).  HBM-bound: 1280 B (u16) read per brick.
+constexpr int kHistBins = 100;               // main.cpp:109
+constexpr int kHistCopies = 32;
+constexpr int kHistPitch = kHistBins + 1;    // entry kHistBins collects what no bin takes
+constexpr int kHistPieces = 80;              // element 637 = cell (7, 7, 7) is the last that is not apron
+constexpr int kHistThreads = 1024;
+
 template <typename T>
-__global__ __launch_bounds__(256) void k_value_histogram(VolumeView vol, unsigned long long *__restrict__ hist)
+__global__ __launch_bounds__(kHistThreads) void k_bin_histogram(VolumeView vol, const uint8_t *__restrict__ bin_of,
+                                                                unsigned long long *__restrict__ out)
 {
-    const uint64_t rows = (uint64_t)vol.nbx * vol.nby * vol.nbz * 64u;
-    unsigned long long zeros = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t brick = i >> 6;
-        const int ly = (int)(i & 7), lz = (int)((i >> 3) & 7);
-        const int bx = (int)(brick % (uint64_t)vol.nbx), by = (int)((brick / (uint64_t)vol.nbx) % (uint64_t)vol.nby),
-                  bz = (int)(brick / ((uint64_t)vol.nbx * vol.nby));
-        const int iy = by * kBrick + ly - kPad, iz = bz * kBrick + lz - kPad;
-        if ((unsigned)iy >= (unsigned)vol.ny || (unsigned)iz >= (unsigned)vol.nz) continue;
-        const T *row = (const T *)vol.bricks + brick * kBrickElems + (lz * kRow + ly) * kRow;
-        uint32_t run_value = 0, run = 0;
-        for (int lx = 0; lx < kBrick; lx++) {
-            const int ix = bx * kBrick + lx - kPad;
-            if ((unsigned)ix >= (unsigned)vol.nx) continue;
-            const uint32_t v = row[lx];
-            if (v == 0u) {
-                zeros++;
-                continue;
+    constexpr int kValues = sizeof(T) == 2 ? 65536 : 256;
+    constexpr int kWords = (int)sizeof(T) * 2;   // dwords that hold 8 voxels
+    __shared__ __align__(16) uint8_t s_bin[kValues];
+    __shared__ uint32_t s_hist[kHistCopies * kHistPitch];
+    // per piece, the elements that are cells holding voxels of the volume, by where the brick sits on an axis:
+    // 0 inside, 1 first brick, 2 last brick, 3 both.  s_yz: y and z together (index y * 4 + z), s_x: x.
+    __shared__ uint8_t s_yz[16][kHistPieces], s_x[4][kHistPieces];
+    const int tid = threadIdx.x;
+    for (int i = tid * 16; i < kValues; i += kHistThreads * 16)
+        *reinterpret_cast<uint4 *>(s_bin + i) = *reinterpret_cast<const uint4 *>(bin_of + i);
+    for (int i = tid; i < kHistCopies * kHistPitch; i += kHistThreads) s_hist[i] = 0u;
+    // all eight cells per axis, but from kPad on in the first brick and up to the volume's end in the last
+    const int end_x = min(kBrick, vol.nx + kPad - kBrick * (vol.nbx - 1));
+    const int end_y = min(kBrick, vol.ny + kPad - kBrick * (vol.nby - 1));
+    const int end_z = min(kBrick, vol.nz + kPad - kBrick * (vol.nbz - 1));
+    for (int i = tid; i < 20 * kHistPieces; i += kHistThreads) {
+        const int variant = i / kHistPieces, p = i - variant * kHistPieces;
+        uint32_t m = 0;
+        for (int j = 0; j < 8; j++) {
+            const int e = p * 8 + j, lz = e / (kRow * kRow), ly = (e / kRow) % kRow, lx = e % kRow;
+            bool ok;
+            if (variant < 16) {
+                const int vy = variant >> 2, vz = variant & 3;
+                ok = lx < kBrick && ly >= ((vy & 1) ? kPad : 0) && ly < ((vy & 2) ? end_y : kBrick) &&
+                     lz >= ((vz & 1) ? kPad : 0) && lz < ((vz & 2) ? end_z : kBrick);
+            } else {
+                const int vx = variant - 16;
+                ok = lx >= ((vx & 1) ? kPad : 0) && lx < ((vx & 2) ? end_x : kBrick);
             }
-            if (v != run_value) {
-                if (run) atomicAdd(&hist[run_value], (unsigned long long)run);
-                run_value = v;
-                run = 0;
-            }
-            run++;
+            m |= (ok ? 1u : 0u) << j;
         }
-        if (run) atomicAdd(&hist[run_value], (unsigned long long)run);
+        if (variant < 16) s_yz[variant][p] = (uint8_t)m;
+        else s_x[variant - 16][p] = (uint8_t)m;
     }
-    for (int o = 32; o > 0; o >>= 1) zeros += __shfl_xor(zeros, o);
-    if ((threadIdx.x & 63) == 0 && zeros) atomicAdd(&hist[0], zeros);
+    __syncthreads();
+
+    uint32_t *mine = s_hist + (tid & (kHistCopies - 1)) * kHistPitch;
+    const uint32_t rows = (uint32_t)vol.nby * (uint32_t)vol.nbz;
+    const int pieces = vol.nbx * kHistPieces;                                   // of a row of bricks along x
+    const int turns = (pieces + 2 * kHistThreads - 1) / (2 * kHistThreads);     // two pieces per lane and turn
+    // The workgroup walks rows blockIdx.x, blockIdx.x + gridDim.x, ...; the loads of the turn after this one are
+    // issued in front of this turn's counting, across the end of a row too.
+    uint32_t next_row = blockIdx.x;
+    int next_turn = 0;
+    auto fetch = [&](uint32_t (*w)[kWords], uint32_t *m) {
+        m[0] = m[1] = 0u;
+        if (next_row >= rows) return;
+        const int by = (int)(next_row % (uint32_t)vol.nby), bz = (int)(next_row / (uint32_t)vol.nby);
+        const uint8_t *yz = s_yz[((by == 0 ? 1 : 0) | (by == vol.nby - 1 ? 2 : 0)) * 4 + ((bz == 0 ? 1 : 0) | (bz == vol.nbz - 1 ? 2 : 0))];
+        const T *bricks = (const T *)vol.bricks + (size_t)next_row * (size_t)vol.nbx * kBrickElems;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int k = (next_turn * 2 + u) * kHistThreads + tid;
+            if (k < pieces) {
+                const int bx = k / kHistPieces, p = k - bx * kHistPieces;
+                m[u] = yz[p] & s_x[(bx == 0 ? 1 : 0) | (bx == vol.nbx - 1 ? 2 : 0)][p];
+                if (m[u]) __builtin_memcpy(w[u], __builtin_assume_aligned(bricks + (size_t)bx * kBrickElems + p * 8, 8 * sizeof(T)), 8 * sizeof(T));
+            }
+        }
+        if (++next_turn == turns) {
+            next_turn = 0;
+            next_row += gridDim.x;
+        }
+    };
+    uint32_t w[2][kWords], m[2];
+    fetch(w, m);
+    for (uint32_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        for (int turn = 0; turn < turns; turn++) {
+            uint32_t w_next[2][kWords], m_next[2];
+            fetch(w_next, m_next);
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                if (m[u] != 0u) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const uint32_t bin = s_bin[voxel_of<T>(w[u], j)];
+                        atomicAdd(&mine[(m[u] >> j) & 1u ? bin : (uint32_t)kHistBins], 1u);
+                    }
+                }
+                m[u] = m_next[u];
+#pragma unroll
+                for (int q = 0; q < kWords; q++) w[u][q] = w_next[u][q];
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < kHistBins) {
+        unsigned long long total = 0;
+        for (int c = 0; c < kHistCopies; c++) total += s_hist[c * kHistPitch + tid];
+        if (total) atomicAdd(&out[tid], total);
+    }
 }
 
 // ---- synthetic phantom ------------------------------------------------------------------------
