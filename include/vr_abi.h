@@ -109,9 +109,12 @@ int vr_histogram(vr_ctx *ctx, float out[100]);
  * segment covers keep their previous value.  reset_state != 0 zeroes it first.  counts[c] == 0
  * leaves channel c untouched.  Meant to be called every frame, as renderCommands does (main.cpp:800-804):
  * graphs equal to the last call's, which leave every bit of the table as it is, return without touching
- * the GPU; changed graphs of up to 256 points in all travel with the kernel launch, and the tables the
- * fast modes skip by are brought up to date on the GPU, for the bricks the change concerns, when the next
- * frame is rendered.  The host waits for nothing (more than 256 points: one copy it waits for). */
+ * the GPU; changed graphs of up to 256 points in all travel with the kernel launch.  A change that leaves
+ * the set of transparent table entries as it is (colours, opacities between non-zero values) does not
+ * disturb frames in flight: the new table is written beside the one they read.  A change of that set orders
+ * the next frame behind them, and the tables the fast modes skip by are brought up to date on the GPU, for
+ * the bricks the change concerns, when that frame is rendered.  The host waits for nothing (more than 256
+ * points: one copy it waits for). */
 int vr_set_transfer_function(vr_ctx *ctx, const vr_ctrl_pt *const points[4], const int counts[4], int reset_state);
 int vr_get_lut(vr_ctx *ctx, float out[1024]);
 /* getIntensity, main.cpp:948-953 */

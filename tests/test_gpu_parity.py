@@ -1258,6 +1258,66 @@ def test_table_changed_between_frames(ctx, oracle, torch):
     assert np.array_equal(ctx.render(w, h), want[-1])
 
 
+def test_tables_in_turn_while_frames_are_in_flight(ctx, oracle, torch):
+    """Colours and opacities edited in front of every frame while the set of transparent entries stays: such a table
+    goes into the next of the library's table slots and the frames in flight finish on theirs.  Every frame of a
+    run without waits equals the checker's frame for its own table -- through more changes than there are slots,
+    several changes between two frames, a change that starts from a zeroed table, and a change of the transparent
+    set in the middle -- and the table read back at the end is the checker's bit for bit."""
+    vox = oracle.phantom(80, np.uint16)
+    vol, _ = oracle.normalize(vox)
+    w, h, samples = 160, 120, 277
+    ctx.upload_volume(vox)
+    ctx.set_sampling(samples, (0, 0, 0, 0))
+    cam = cf.CAMERAS["h30_v20"]
+    ctx.set_camera(*cam)
+    vp, m = oracle.camera(cam[0], cam[1], w, h)
+    xs = (0.0, 120.0, 300.0, 483.0)
+
+    def graphs(k, thr=120.0):
+        a = 0.05 + 0.03 * (k % 5)
+        return [list(zip(xs, (0, .9 - .05 * (k % 7), 1, 1))), list(zip(xs, (0, .3, .8 - .04 * (k % 3), 1))),
+                list(zip(xs, (0, .1 + .02 * k, .5, 1))), list(zip((0.0, thr, 300.0, 483.0), (0, 0, a, .6 + .02 * (k % 4))))]
+
+    # (graphs, reset_state, frame rendered behind the call)
+    steps = [(graphs(k), False, True) for k in range(7)]
+    steps += [(graphs(10 + k), False, k == 5) for k in range(6)]           # six calls, one frame
+    steps += [(graphs(20), True, True)]                                    # from a zeroed table, same set
+    steps += [(graphs(21, thr=170.0), False, True)]                        # the transparent range moves: tables rebuilt
+    steps += [(graphs(22 + k, thr=170.0), False, True) for k in range(5)]  # and slots in turn again behind it
+    lut = np.zeros((256, 4), np.float32)
+    ctx.update_transfer_function(graphs(0), reset_state=True)
+    oracle.lut_update(lut, graphs(0))
+    ctx.set_mode(1)
+    ctx.render(w, h)                                                       # occupancy tables built for this set
+    ctx.set_pipeline(2)
+    want, bufs = [], []
+    for g, reset, framed in steps:
+        if framed:
+            bufs.append(torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda"))
+    torch.cuda.synchronize()
+    at = 0
+    for g, reset, framed in steps:
+        if reset:
+            lut[:] = 0
+        oracle.lut_update(lut, g)
+        ctx.update_transfer_function(g, reset_state=reset)
+        if framed:
+            want.append(oracle.render(vol, lut, vp[4:8], m, w, h, samples))
+            ctx.render_device(w, h, bufs[at].data_ptr())
+            at += 1
+    ctx.synchronize()
+    ctx.set_pipeline(1)
+    for k in range(len(want)):
+        got = bufs[k].cpu().numpy()
+        assert np.array_equal(got, want[k]), (k, cf.frame_report(got, want[k]))
+    assert sum(not np.array_equal(want[k], want[k + 1]) for k in range(len(want) - 1)) >= len(want) - 2
+    assert cf.same_bits(ctx.transfer_function(), lut)
+    for mode in (2, 0):                                                    # the other marches read the current slot too
+        ctx.set_mode(mode)
+        assert np.array_equal(ctx.render(w, h), want[-1]), mode
+
+
 def test_many_control_points_take_the_staged_path(ctx, oracle):
     """More points than travel with the launch (256): the graphs go through the staging buffer; same table."""
     xs = np.linspace(0.0, 480.0, 300)

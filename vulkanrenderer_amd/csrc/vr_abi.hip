@@ -82,7 +82,20 @@ struct vr_ctx {
     float max_value = 0.0f, inv_hi = 0.0f, inv_lo = 0.0f;
 
     // transfer function
-    float *lut = nullptr;  // 256 x RGBA on the device, persists like `transferFunction`
+    float *lut = nullptr;  // 256 x RGBA on the device, persists like `transferFunction`: the current slot of lut_store
+    // Tables in turn.  A call that changes the table but not the set of transparent entries (the host builds the
+    // table too and knows) writes the next slot and lets the frames in flight finish on theirs, so the editor's
+    // every-frame changes of colours and opacities do not serialise the frames; `lut` and `lut_info` point at the
+    // current slot.  slot_frame: value of `frames` when a frame last took the slot.
+    static constexpr int kLutSlots = 4;
+    float *lut_store = nullptr;
+    vr::LutInfo *info_store = nullptr;
+    int lut_slot = 0;
+    uint64_t slot_frame[kLutSlots] = {0, 0, 0, 0};
+    float host_lut[1024] = {0};         // the table as the host builds it beside the device (bit for bit the same arithmetic)
+    bool host_lut_valid = true;         // false once a graph addressed a pixel outside the table
+    uint8_t built_bad[vr::kLutLds] = {0};   // per entry of the LDS table: not transparent, as of the last call that marked the occupancy dirty
+    bool built_bad_valid = false;
     vr::CtrlPt *d_pts = nullptr;
     size_t d_pts_cap = 0;
     // The graphs of the last call and whether the table is what they make of a zeroed table.  The builder
@@ -497,7 +510,7 @@ int refresh_occupancy(vr_ctx *ctx)
     drain(ctx);   // frames still being finished read the tables rebuilt here
     const float4 border = make_float4(ctx->border[0], ctx->border[1], ctx->border[2], ctx->border[3]);
     hipLaunchKernelGGL(vr::k_lut_derive, dim3(1), dim3(256), 0, ctx->stream, reinterpret_cast<const float4 *>(ctx->lut), border,
-                       ctx->shading ? vr::shade_bound(ctx->scene) : 0.0f, ctx->occupancy_force ? 1 : 0, ctx->lut_info, ctx->occ,
+                       ctx->shading ? vr::shade_bound(ctx->scene) : 0.0f, ctx->occupancy_force ? 1 : 0, ctx->lut_info, ctx->lut_info, ctx->occ,
                        ctx->d_occ_count);
     const unsigned bricks = (unsigned)ctx->brick_count;
     hipLaunchKernelGGL(vr::k_classify_bricks, dim3((bricks + 255) / 256), dim3(256), 0, ctx->stream, ctx->cells, bricks, ctx->inv_hi,
@@ -607,6 +620,7 @@ void launch_frame_as(vr_ctx *ctx, const vr::FrameParams &fp, uint32_t *d_out, co
     hipStream_t s = ctx->stream;
     const int slot = (int)(ctx->frames % (uint64_t)vr_ctx::kRing);
     ctx->frames++;
+    ctx->slot_frame[ctx->lut_slot] = ctx->frames;
     (void)hipEventRecord(ctx->ring_a[slot], s);
     const int mode = (ctx->mode == VR_MODE_FAST && ctx->fast_fallback) ? VR_MODE_REFERENCE_SKIP : ctx->mode;
     if (mode == VR_MODE_REFERENCE_ORDER) {
@@ -721,9 +735,9 @@ int vr_create(int device, vr_ctx **out)
     ctx->device = device;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
-        dev_alloc(&ctx->lut, 1024 * sizeof(float)) != hipSuccess ||
+        dev_alloc(&ctx->lut_store, (size_t)vr_ctx::kLutSlots * 1024 * sizeof(float)) != hipSuccess ||
         dev_alloc(&ctx->counters, sizeof(vr::Counters)) != hipSuccess ||
-        dev_alloc(&ctx->lut_info, sizeof(vr::LutInfo)) != hipSuccess ||
+        dev_alloc(&ctx->info_store, (size_t)vr_ctx::kLutSlots * sizeof(vr::LutInfo)) != hipSuccess ||
         dev_alloc(&ctx->occ, 6 * sizeof(int)) != hipSuccess ||
         dev_alloc(&ctx->d_occ_count, sizeof(uint32_t)) != hipSuccess ||
         dev_alloc(&ctx->d_data_max, sizeof(uint32_t)) != hipSuccess ||
@@ -732,13 +746,16 @@ int vr_create(int device, vr_ctx **out)
         hipEventRecord(ctx->occ_ready, ctx->stream) != hipSuccess ||
         hipHostMalloc((void **)&ctx->probe_word, 64, hipHostMallocDefault) != hipSuccess ||
         hipHostGetDevicePointer((void **)&ctx->probe_dev, ctx->probe_word, 0) != hipSuccess ||
-        hipMemset(ctx->lut, 0, 1024 * sizeof(float)) != hipSuccess ||  // main.cpp:110: zero-initialised table
+        hipMemset(ctx->lut_store, 0, (size_t)vr_ctx::kLutSlots * 1024 * sizeof(float)) != hipSuccess ||  // main.cpp:110: zero-initialised table
+        hipMemset(ctx->info_store, 0, (size_t)vr_ctx::kLutSlots * sizeof(vr::LutInfo)) != hipSuccess ||
         hipMemset(ctx->counters, 0, sizeof(vr::Counters)) != hipSuccess ||
         hipMemcpyToSymbol(HIP_SYMBOL(vr::d_phantom), vr::PHANTOM, sizeof(vr::PHANTOM)) != hipSuccess) {
         vr_destroy(ctx);
         return VR_ERR_HIP;
     }
     *ctx->probe_word = 0ull;
+    ctx->lut = ctx->lut_store;
+    ctx->lut_info = ctx->info_store;
     if (const char *e = std::getenv("VR_TEST_FAIL_ALLOC")) ctx->fail_alloc_in = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("VR_TILE_CLIP")) ctx->tile_clip = std::atoi(e) != 0;
     if (const char *e = std::getenv("VR_TILE_ORDER")) {
@@ -803,14 +820,14 @@ int vr_destroy(vr_ctx *ctx)
     }
     if (ctx->frame_done) (void)hipEventDestroy(ctx->frame_done);
     if (ctx->tail_stream) (void)hipStreamDestroy(ctx->tail_stream);
-    if (ctx->lut) (void)dev_free(ctx->lut);
+    if (ctx->lut_store) (void)dev_free(ctx->lut_store);
     if (ctx->d_pts) (void)dev_free(ctx->d_pts);
     if (ctx->counters) (void)dev_free(ctx->counters);
     if (ctx->frame) (void)dev_free(ctx->frame);
     if (ctx->partial) (void)dev_free(ctx->partial);
     if (ctx->queue) (void)dev_free(ctx->queue);
     if (ctx->long_queue) (void)dev_free(ctx->long_queue);
-    if (ctx->lut_info) (void)dev_free(ctx->lut_info);
+    if (ctx->info_store) (void)dev_free(ctx->info_store);
     if (ctx->occ) (void)dev_free(ctx->occ);
     if (ctx->d_occ_count) (void)dev_free(ctx->d_occ_count);
     if (ctx->d_data_max) (void)dev_free(ctx->d_data_max);
@@ -1062,6 +1079,52 @@ int vr_histogram(vr_ctx *ctx, float out[100])
     return VR_OK;
 }
 
+namespace {
+// k_lut_update on the host, statement for statement (updateTransferFunction, main.cpp:643-686): the same IEEE
+// operations in the same order, so the table is the device's bit for bit.  Returns false when a graph
+// addresses a pixel outside the table (the device then flags the table and so must the caller).
+bool host_lut_update(float *lut, const std::vector<vr::CtrlPt> &pts, const int offs[5])
+{
+    bool ok = true;
+    for (int ch = 0; ch < 4; ch++) {
+        const int begin = offs[ch], cnt = offs[ch + 1] - offs[ch];
+        if (cnt < 1) continue;
+        const float x_last = pts[(size_t)begin + cnt - 1].x;
+        for (int j = 1; j < cnt; j++) {
+            const vr::CtrlPt ga = pts[(size_t)begin + j - 1], gb = pts[(size_t)begin + j];
+            const float xa = (ga.x / x_last) * 255.0f;
+            const float xb = (gb.x / x_last) * 255.0f;
+            const float dir = gb.intensity - ga.intensity;
+            const float total = xb - xa + 1.0f;
+            uint32_t count = 0;
+            if (total >= 1.0f) count = total >= 4294967296.0f ? 0xFFFFFFFFu : (uint32_t)total;
+            if (count > 1024u) {
+                ok = false;
+                count = 0;
+            }
+            for (uint32_t k = 0; k < count; k++) {
+                const float val = ga.intensity + dir * ((float)k / (total - 1.0f));
+                const float pixel = xa + (float)k;
+                if (pixel >= 0.0f && pixel < 256.0f) lut[(int)pixel * 4 + ch] = val;
+                else ok = false;
+            }
+        }
+    }
+    return ok;
+}
+
+// Per entry of the marches' LDS table (two border entries, the 256 of the table, two border entries): the entry
+// is not transparent, by k_lut_derive's test.
+void bad_entries(const float *lut, const float border[4], uint8_t *bad)
+{
+    for (int i = 0; i < vr::kLutLds; i++) {
+        const float *v = (i >= 2 && i < 258) ? lut + (size_t)(i - 2) * 4 : border;
+        const bool finite = std::isfinite(v[0]) && std::isfinite(v[1]) && std::isfinite(v[2]);
+        bad[i] = (v[3] != 0.0f || !finite) ? 1 : 0;
+    }
+}
+}  // namespace
+
 int vr_set_transfer_function(vr_ctx *ctx, const vr_ctrl_pt *const points[4], const int counts[4], int reset_state)
 {
     if (!ctx || !points || !counts) return fail(ctx, VR_ERR_ARG, "null argument");
@@ -1089,10 +1152,49 @@ int vr_set_transfer_function(vr_ctx *ctx, const vr_ctrl_pt *const points[4], con
     ctx->table_from_zero = reset_state != 0;
     ctx->last_pts = packed;
     std::memcpy(ctx->last_offs, offs, sizeof offs);
-    ctx->occupancy_dirty = true;
     ctx->table_epoch++;
     ctx->fast_fallback = false;
-    drain(ctx);   // frames still being finished read the table
+
+    // The table on the host, to see whether the set of transparent entries moves: the occupancy tables depend
+    // on the table through that set alone.
+    if (reset_state) {
+        std::memset(ctx->host_lut, 0, sizeof ctx->host_lut);
+        ctx->host_lut_valid = true;
+    }
+    if (!host_lut_update(ctx->host_lut, packed, offs)) ctx->host_lut_valid = false;
+    uint8_t bad[vr::kLutLds];
+    bad_entries(ctx->host_lut, ctx->border, bad);
+    const bool set_kept = ctx->host_lut_valid && ctx->built_bad_valid && !ctx->occupancy_dirty &&
+                          std::memcmp(bad, ctx->built_bad, sizeof bad) == 0 && packed.size() <= (size_t)vr::kLutArgPoints;
+    if (set_kept) {
+        // Same set: the occupancy tables stay, and so do the frames in flight -- the table goes into the next
+        // slot (a copy of this one, or zeros, updated there) together with what the marches derive from it.
+        const int next = (ctx->lut_slot + 1) % vr_ctx::kLutSlots;
+        if (ctx->slot_frame[next] != 0 && ctx->frames - ctx->slot_frame[next] < (uint64_t)vr_ctx::kSets)
+            drain(ctx);   // a frame that read the slot may still be finished (several table calls between two frames)
+        float *lut = ctx->lut_store + (size_t)next * 1024;
+        vr::LutInfo *info = ctx->info_store + next;
+        if (reset_state) VR_HIP(ctx, hipMemsetAsync(lut, 0, 1024 * sizeof(float), ctx->stream));
+        else VR_HIP(ctx, hipMemcpyAsync(lut, ctx->lut, 1024 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+        if (!packed.empty()) {
+            vr::LutPointsArg arg;
+            std::memcpy(arg.p, packed.data(), packed.size() * sizeof(vr::CtrlPt));
+            hipLaunchKernelGGL((vr::k_lut_update<true>), dim3(1), dim3(256), 0, ctx->stream, lut, (const vr::CtrlPt *)nullptr, arg, offs[0],
+                               offs[1], offs[2], offs[3], offs[4], ctx->counters);
+        }
+        const float4 border = make_float4(ctx->border[0], ctx->border[1], ctx->border[2], ctx->border[3]);
+        hipLaunchKernelGGL(vr::k_lut_derive, dim3(1), dim3(256), 0, ctx->stream, reinterpret_cast<const float4 *>(lut), border,
+                           ctx->shading ? vr::shade_bound(ctx->scene) : 0.0f, 0, ctx->lut_info, info, ctx->occ, ctx->d_occ_count);
+        VR_HIP(ctx, hipGetLastError());
+        ctx->lut = lut;
+        ctx->lut_info = info;
+        ctx->lut_slot = next;
+        return VR_OK;
+    }
+    std::memcpy(ctx->built_bad, bad, sizeof bad);
+    ctx->built_bad_valid = true;
+    ctx->occupancy_dirty = true;
+    drain(ctx);   // frames still being finished read the table and the occupancy tables
     if (reset_state) VR_HIP(ctx, hipMemsetAsync(ctx->lut, 0, 1024 * sizeof(float), ctx->stream));
     if (packed.empty()) return VR_OK;
     if (packed.size() <= (size_t)vr::kLutArgPoints) {

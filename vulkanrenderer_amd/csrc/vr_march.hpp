@@ -43,11 +43,13 @@ constexpr float kUlpHalf = 5.9604644775390625e-08f;  // 2^-24
 
 // One block.  Derives LutInfo from the table and the border colour.
 // shade_hi: largest value the local illumination adds to a tap's colour (0 when it is off).
-// force: the occupancy tables have to be rebuilt whatever the table says (new volume; `info` may be
+// prev: what was derived from the table the occupancy tables were built for (may be `info` itself: it is read
+// before anything is written).
+// force: the occupancy tables have to be rebuilt whatever the table says (new volume; `prev` may be
 // uninitialised then).  When a rebuild is due the bounding box of the occupied bricks and the length of the
 // list of surface bricks are reset here, in front of the kernels that rebuild them.
 __global__ __launch_bounds__(256) void k_lut_derive(const float4 *__restrict__ lut, float4 border, float shade_hi, int force,
-                                                   LutInfo *info, int *occ, uint32_t *occ_count)
+                                                   const LutInfo *prev, LutInfo *info, int *occ, uint32_t *occ_count)
 {
     __shared__ uint32_t s_bad[kLutLds], s_old[kLutLds];
     __shared__ float s_min[3][256], s_max[3][256];
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(256) void k_lut_derive(const float4 *__restrict__ l
         if (i >= 2 && i < 258) v = lut[i - 2];
         const bool finite = isfinite(v.x) && isfinite(v.y) && isfinite(v.z);
         s_bad[i] = (v.w != 0.0f || !finite) ? 1u : 0u;
-        s_old[i] = force ? 2u : info->bad_prefix[i + 1] - info->bad_prefix[i];   // 2: differs from any new value
+        s_old[i] = force ? 2u : prev->bad_prefix[i + 1] - prev->bad_prefix[i];   // 2: differs from any new value
         if (!finite || !(v.w >= 0.0f && v.w <= 1.0f)) ok = 0;
         const float ch[3] = {v.x, v.y, v.z};
         for (int c = 0; c < 3; c++) {
