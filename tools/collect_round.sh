@@ -26,6 +26,12 @@ for e in cabi; do
   timeout -k 10 300 python3 bench.py --exchange $e --steps 120 --no-cpu-baseline > "$out/bench_c4_$e.json" 2> "$out/bench_c4_$e.err" || exit 1
   timeout -k 10 300 python3 bench.py --config c5 --exchange $e --steps 120 --no-cpu-baseline > "$out/bench_c5_$e.json" 2> "$out/bench_c5_$e.err" || exit 1
 done
+bash tools/histogram_profile.sh "$tag" 2048 > "$out/histogram_profile.txt" 2>&1 || exit 1
+timeout -k 10 100 python3 tools/histogram_time.py 256 512 1024 2048 > "$out/histogram_times.txt" 2>&1 || exit 1
+timeout -k 10 200 python3 tools/upload_time.py 512 1024 1536 > "$out/upload_times.txt" 2>&1 || exit 1
+timeout -k 10 200 python3 tools/timeline.py > "$out/lane_march_timeline.txt" 2>&1 || exit 1
+cp gpurun_out/timeline_counts.json "$out/lane_march_wave_counts.json"
+timeout -k 10 200 python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$out/bench_as_the_driver_runs_it.json" 2> "$out/bench_as_the_driver_runs_it.err" || exit 1
 for m in "" "--in-flight 2" "--pageable"; do
   timeout -k 10 200 ./examples/orbit --phantom 2048 --size 3840x2160 --frames 360 --samples 7094 --mode 1 $m >> "$out/orbit_hand_off.txt" 2>&1 || exit 1
 done
