@@ -16,6 +16,8 @@ pass() {
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 pass tcc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum
+pass sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAIT_ANY
+pass sq2 SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT
 cd "$root"
 python3 tools/kernel_times.py "$out/kt" | tee "$out/kernel_times.txt"
-python3 tools/pmc_summary.py "$out/tcc" "$out/fetch" "$out/write" | tee "$out/pmc.txt"
+python3 tools/pmc_summary.py "$out/tcc" "$out/fetch" "$out/write" "$out/sq1" "$out/sq2" | tee "$out/pmc.txt"
