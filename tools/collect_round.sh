@@ -1,5 +1,5 @@
 #!/bin/bash
-# Everything the round's measurements in DESIGN.md / profiles/ come from, on the GPU box:
+# Everything the measurements kept under profiles/ come from, on the GPU box:
 # usage: bash tools/collect_round.sh <tag>   -> gpurun_out/round_<tag>/ and gpurun_out/prof_<tag>/
 set -u
 tag=${1:-rX}

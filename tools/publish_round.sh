@@ -1,6 +1,6 @@
 #!/bin/bash
-# Run in the repository after `bash tools/collect_round.sh <tag>` on the GPU box: copies the summaries the documents
-# cite from gpurun_out/ into profiles/<tag>/ and refreshes profiles/traffic.json.
+# Run in the repository after `bash tools/collect_round.sh <tag>` on the GPU box: copies the summaries kept in the repository
+# from gpurun_out/ into profiles/<tag>/ and refreshes profiles/traffic.json.
 # usage: bash tools/publish_round.sh <tag>
 set -eu
 tag=${1:?tag}
