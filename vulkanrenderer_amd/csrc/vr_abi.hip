@@ -1232,6 +1232,12 @@ int vr_get_lut(vr_ctx *ctx, float out[1024])
     VR_HIP(ctx, hipMemcpyAsync(&c, ctx->counters, sizeof c, hipMemcpyDeviceToHost, ctx->stream));
     VR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (c.lut_error) return fail(ctx, VR_ERR_ARG, "a control graph addressed a pixel outside the 256-entry table");
+    // the table the host builds beside the device's (it decides whether a change concerns the occupancy tables)
+    // has to be the same table; entries that are not numbers on both sides count as equal
+    if (ctx->host_lut_valid)
+        for (int i = 0; i < 1024; i++)
+            if (std::memcmp(&out[i], &ctx->host_lut[i], sizeof(float)) != 0 && !(std::isnan(out[i]) && std::isnan(ctx->host_lut[i])))
+                return fail(ctx, VR_ERR_STATE, "the host's copy of the table differs from the device's at entry " + std::to_string(i / 4));
     return VR_OK;
 }
 
