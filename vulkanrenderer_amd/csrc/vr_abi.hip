@@ -526,7 +526,7 @@ int refresh_occupancy(vr_ctx *ctx)
     hipLaunchKernelGGL(vr::k_pack_skip, dim3((skip_words + 255) / 256), dim3(256), 0, ctx->stream, ctx->lut_info, ctx->empty[0],
                        ctx->empty[1], ctx->empty[2], ctx->lx[0], ctx->ly[0], ctx->lz[0], ctx->lx[1], ctx->ly[1], ctx->lx[2], ctx->ly[2],
                        ctx->skip);
-    const unsigned micro_blocks = (unsigned)std::min<size_t>((ctx->brick_count + 3) / 4, 1u << 18);
+    const unsigned micro_blocks = (unsigned)std::min<size_t>((ctx->brick_count + 255) / 256, 1u << 14);   // a workgroup sifts 256 bricks at a time
     if (ctx->dtype == VR_DTYPE_U8)
         hipLaunchKernelGGL((vr::k_classify_micro<uint8_t>), dim3(micro_blocks), dim3(256), 0, ctx->stream, (const uint8_t *)ctx->bricks,
                            ctx->empty[0], ctx->cells, bricks, ctx->inv_hi, ctx->inv_lo, ctx->lut_info, ctx->micro);
@@ -534,8 +534,8 @@ int refresh_occupancy(vr_ctx *ctx)
         hipLaunchKernelGGL((vr::k_classify_micro<uint16_t>), dim3(micro_blocks), dim3(256), 0, ctx->stream, (const uint16_t *)ctx->bricks,
                            ctx->empty[0], ctx->cells, bricks, ctx->inv_hi, ctx->inv_lo, ctx->lut_info, ctx->micro);
     const unsigned cubes4 = (unsigned)(((ctx->lx[0] + 3) / 4) * ((ctx->ly[0] + 3) / 4) * ((ctx->lz[0] + 3) / 4));
-    hipLaunchKernelGGL(vr::k_list_occupied, dim3((cubes4 + 3) / 4), dim3(256), 0, ctx->stream, ctx->lut_info, ctx->empty[0], ctx->lx[0],
-                       ctx->ly[0], ctx->lz[0], ctx->occ_list, ctx->d_occ_count);
+    hipLaunchKernelGGL(vr::k_list_occupied, dim3((cubes4 + vr::kListWaves - 1) / vr::kListWaves), dim3(64 * vr::kListWaves), 0, ctx->stream, ctx->lut_info, ctx->empty[0], ctx->empty[1],
+                       ctx->lx[0], ctx->ly[0], ctx->lz[0], ctx->occ_list, ctx->d_occ_count);
     VR_HIP(ctx, hipGetLastError());
     VR_HIP(ctx, hipEventRecord(ctx->occ_ready, ctx->stream));
     ctx->occupancy_dirty = false;

@@ -209,46 +209,53 @@ __global__ __launch_bounds__(256) void k_classify_micro(const T *__restrict__ br
     const int lane = threadIdx.x & 63;
     const uint32_t waves = gridDim.x * 4u;
     const int bx = (lane & 3) * 2, by = ((lane >> 2) & 3) * 2, bz = (lane >> 4) * 2;
-    for (uint32_t brick = blockIdx.x * 4u + (threadIdx.x >> 6); brick < brick_count; brick += waves) {
-        {
-            const uint32_t mm = cells[brick];
+    // 64 bricks at a time, one per lane, to find those the change concerns (few: the bricks whose values straddle
+    // the entries that changed); the wave then takes these one after the other
+    for (uint32_t base = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 64u; base < brick_count; base += waves * 64u) {
+        bool todo = false;
+        const uint32_t mine = base + (uint32_t)lane;
+        if (mine < brick_count) {
+            const uint32_t mm = cells[mine];
             const float lo = (float)(mm & 0xffffu), hi = (float)(mm >> 16);
             int first, last;
             tf_entry_range(__builtin_fmaf(lo, inv_hi, lo * inv_lo), __builtin_fmaf(hi, inv_hi, hi * inv_lo), first, last);
-            if (last < chg_first || first > chg_last) continue;   // nothing this brick reads has changed: its word stands
-        }
-        if ((empty0[brick >> 5] >> (brick & 31)) & 1u) {
-            if (lane == 0) micro[brick] = ~0ull;
-            continue;
-        }
-        const T *src = bricks + (size_t)brick * kBrickElems + (bz * kRow + by) * kRow + bx;
-        uint32_t mn = 0xffffffffu, mx = 0;
-#pragma unroll
-        for (int z = 0; z < 3; z++)
-#pragma unroll
-            for (int y = 0; y < 3; y++)
-#pragma unroll
-                for (int x = 0; x < 3; x++) {
-                    const uint32_t v = src[(z * kRow + y) * kRow + x];
-                    mn = v < mn ? v : mn;
-                    mx = v > mx ? v : mx;
-                }
-        const float lo = (float)mn, hi = (float)mx;
-        int first, last;
-        tf_entry_range(__builtin_fmaf(lo, inv_hi, lo * inv_lo), __builtin_fmaf(hi, inv_hi, hi * inv_lo), first, last);
-        const bool empty = info->bad_prefix[last + 1] == info->bad_prefix[first];
-        unsigned long long mask = __ballot(empty);
-#ifdef VR_COARSE_MICRO
-        {   // experiment: blocks of 4^3 cells (a group of 8 blocks is empty only if all of them are)
-            unsigned long long gm = 0;
-            for (int k = 0; k < 8; k++) {
-                const int x = ((lane & 3) & ~1) | (k & 1), y = (((lane >> 2) & 3) & ~1) | ((k >> 1) & 1), z = ((lane >> 4) & ~1) | (k >> 2);
-                gm |= 1ull << ((z << 4) | (y << 2) | x);
+            todo = !(last < chg_first || first > chg_last);   // else nothing this brick reads has changed: its word stands
+            if (todo && ((empty0[mine >> 5] >> (mine & 31)) & 1u)) {
+                micro[mine] = ~0ull;
+                todo = false;
             }
-            mask = __ballot((mask & gm) == gm);
         }
+        for (unsigned long long left = __ballot(todo); left != 0ull; left &= left - 1ull) {
+            const uint32_t brick = base + (uint32_t)__builtin_ctzll(left);
+            const T *src = bricks + (size_t)brick * kBrickElems + (bz * kRow + by) * kRow + bx;
+            uint32_t mn = 0xffffffffu, mx = 0;
+#pragma unroll
+            for (int z = 0; z < 3; z++)
+#pragma unroll
+                for (int y = 0; y < 3; y++)
+#pragma unroll
+                    for (int x = 0; x < 3; x++) {
+                        const uint32_t v = src[(z * kRow + y) * kRow + x];
+                        mn = v < mn ? v : mn;
+                        mx = v > mx ? v : mx;
+                    }
+            const float lo = (float)mn, hi = (float)mx;
+            int first, last;
+            tf_entry_range(__builtin_fmaf(lo, inv_hi, lo * inv_lo), __builtin_fmaf(hi, inv_hi, hi * inv_lo), first, last);
+            const bool empty = info->bad_prefix[last + 1] == info->bad_prefix[first];
+            unsigned long long mask = __ballot(empty);
+#ifdef VR_COARSE_MICRO
+            {   // experiment: blocks of 4^3 cells (a group of 8 blocks is empty only if all of them are)
+                unsigned long long gm = 0;
+                for (int k = 0; k < 8; k++) {
+                    const int x = ((lane & 3) & ~1) | (k & 1), y = (((lane >> 2) & 3) & ~1) | ((k >> 1) & 1), z = ((lane >> 4) & ~1) | (k >> 2);
+                    gm |= 1ull << ((z << 4) | (y << 2) | x);
+                }
+                mask = __ballot((mask & gm) == gm);
+            }
 #endif
-        if (lane == 0) micro[brick] = mask;
+            if (lane == 0) micro[brick] = mask;
+        }
     }
 }
 
@@ -412,32 +419,49 @@ constexpr int kRangeShift = VR_RANGE_SHIFT;
 // can be the first or last occupied brick of a ray, whatever the camera.  One wave looks at one cube of
 // 4^3 bricks and appends its finds in one piece, so bricks that are neighbours in space are neighbours
 // in the list (k_splat_bricks merges the ranges of a block's bricks per tile before it goes to memory).
-__global__ __launch_bounds__(256) void k_list_occupied(const LutInfo *__restrict__ info, const uint32_t *__restrict__ empty0, int nbx,
-                                                      int nby, int nbz, uint32_t *__restrict__ list, uint32_t *count)
+constexpr int kListWaves = 16;   // cubes a workgroup of k_list_occupied looks at
+__global__ __launch_bounds__(64 * kListWaves) void k_list_occupied(const LutInfo *__restrict__ info, const uint32_t *__restrict__ empty0,
+                                                                  const uint32_t *__restrict__ empty1, int nbx, int nby, int nbz,
+                                                                  uint32_t *__restrict__ list, uint32_t *count)
 {
     if (!info->changed) return;
-    const int lane = threadIdx.x & 63;
+    __shared__ uint32_t s_finds[kListWaves], s_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gx_n = (nbx + 3) >> 2, gy_n = (nby + 3) >> 2, gz_n = (nbz + 3) >> 2;
-    const uint32_t group = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (group >= (uint32_t)(gx_n * gy_n * gz_n)) return;    // whole waves leave together
-    const int gx = (int)(group % (uint32_t)gx_n), gy = (int)((group / (uint32_t)gx_n) % (uint32_t)gy_n),
-              gz = (int)(group / (uint32_t)(gx_n * gy_n));
-    const int bx = gx * 4 + (lane & 3), by = gy * 4 + ((lane >> 2) & 3), bz = gz * 4 + (lane >> 4);
-    auto empty_at = [&](int x, int y, int z) -> bool {
-        if ((unsigned)x >= (unsigned)nbx || (unsigned)y >= (unsigned)nby || (unsigned)z >= (unsigned)nbz) return true;
-        const uint32_t b = (uint32_t)((z * nby + y) * nbx + x);
-        return (empty0[b >> 5] >> (b & 31)) & 1u;
-    };
+    const uint32_t group = blockIdx.x * (uint32_t)kListWaves + (uint32_t)wave;
     bool keep = false;
-    if (bx < nbx && by < nby && bz < nbz && !empty_at(bx, by, bz))
-        keep = empty_at(bx - 1, by, bz) || empty_at(bx + 1, by, bz) || empty_at(bx, by - 1, bz) || empty_at(bx, by + 1, bz) ||
-               empty_at(bx, by, bz - 1) || empty_at(bx, by, bz + 1);
+    int bx = 0, by = 0, bz = 0;
+    // the cube is a cell of the pyramid's next level (same grid, same numbering): most of a volume is empty cubes
+    if (group < (uint32_t)(gx_n * gy_n * gz_n) && !((empty1[group >> 5] >> (group & 31)) & 1u)) {
+        const int gx = (int)(group % (uint32_t)gx_n), gy = (int)((group / (uint32_t)gx_n) % (uint32_t)gy_n),
+                  gz = (int)(group / (uint32_t)(gx_n * gy_n));
+        bx = gx * 4 + (lane & 3);
+        by = gy * 4 + ((lane >> 2) & 3);
+        bz = gz * 4 + (lane >> 4);
+        auto empty_at = [&](int x, int y, int z) -> bool {
+            if ((unsigned)x >= (unsigned)nbx || (unsigned)y >= (unsigned)nby || (unsigned)z >= (unsigned)nbz) return true;
+            const uint32_t b = (uint32_t)((z * nby + y) * nbx + x);
+            return (empty0[b >> 5] >> (b & 31)) & 1u;
+        };
+        if (bx < nbx && by < nby && bz < nbz && !empty_at(bx, by, bz))
+            keep = empty_at(bx - 1, by, bz) || empty_at(bx + 1, by, bz) || empty_at(bx, by - 1, bz) || empty_at(bx, by + 1, bz) ||
+                   empty_at(bx, by, bz - 1) || empty_at(bx, by, bz + 1);
+    }
+    // one addition to the list's length per workgroup: additions on one word take their turn
     const unsigned long long mask = __ballot(keep);
-    if (mask == 0ull) return;
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(count, (uint32_t)__popcll(mask));
-    base = (uint32_t)__shfl((int)base, 0);
-    if (keep) list[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)((bz * nby + by) * nbx + bx);
+    if (lane == 0) s_finds[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (int k = 0; k < kListWaves; k++) total += s_finds[k];
+        s_base = total ? atomicAdd(count, total) : 0u;
+    }
+    __syncthreads();
+    if (keep) {
+        uint32_t base = s_base;
+        for (int k = 0; k < wave; k++) base += s_finds[k];
+        list[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)((bz * nby + by) * nbx + bx);
+    }
 }
 
 // Only bricks a ray can reach first or leave last have something to say.  A ray enters a brick through
