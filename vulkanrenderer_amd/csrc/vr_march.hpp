@@ -54,6 +54,7 @@ __global__ __launch_bounds__(256) void k_lut_derive(const float4 *__restrict__ l
     __shared__ uint32_t s_bad[kLutLds], s_old[kLutLds];
     __shared__ float s_min[3][256], s_max[3][256];
     __shared__ uint32_t s_ok[256];
+    __shared__ int s_first, s_last;
     const int tid = threadIdx.x;
     float mn[3] = {border.x, border.y, border.z}, mx[3] = {border.x, border.y, border.z};
     uint32_t ok = 1;
@@ -75,19 +76,35 @@ __global__ __launch_bounds__(256) void k_lut_derive(const float4 *__restrict__ l
         s_max[c][tid] = mx[c];
     }
     s_ok[tid] = ok;
+    if (tid == 0) {
+        s_first = kLutLds;
+        s_last = -1;
+    }
+    __syncthreads();
+    // prefix counts and the range of entries whose badness changed, every lane its own entries
+    for (int i = tid; i <= kLutLds; i += 256) {
+        uint32_t run = 0;
+        for (int j = 0; j < i; j++) run += s_bad[j];
+        info->bad_prefix[i] = run;
+        if (i < kLutLds && s_bad[i] != s_old[i]) {
+            atomicMin(&s_first, i);
+            atomicMax(&s_last, i);
+        }
+    }
+    // colour ranges and the all-is-well flag: folded pairwise
+    for (int stride = 128; stride > 0; stride >>= 1) {
+        __syncthreads();
+        if (tid < stride) {
+            for (int c = 0; c < 3; c++) {
+                if (s_min[c][tid + stride] < s_min[c][tid]) s_min[c][tid] = s_min[c][tid + stride];
+                if (s_max[c][tid + stride] > s_max[c][tid]) s_max[c][tid] = s_max[c][tid + stride];
+            }
+            s_ok[tid] &= s_ok[tid + stride];
+        }
+    }
     __syncthreads();
     if (tid == 0) {
-        uint32_t run = 0;
-        int first = kLutLds, last = -1;
-        for (int i = 0; i < kLutLds; i++) {
-            info->bad_prefix[i] = run;
-            run += s_bad[i];
-            if (s_bad[i] != s_old[i]) {
-                first = i < first ? i : first;
-                last = i;
-            }
-        }
-        info->bad_prefix[kLutLds] = run;
+        const int first = s_first, last = s_last;
         info->changed = last >= 0 ? 1u : 0u;
         info->chg_first = first;
         info->chg_last = last;
@@ -96,15 +113,8 @@ __global__ __launch_bounds__(256) void k_lut_derive(const float4 *__restrict__ l
             occ[3] = occ[4] = occ[5] = -1;
             *occ_count = 0u;
         }
-        uint32_t all_ok = 1;
+        const uint32_t all_ok = s_ok[0];
         float lo[3] = {s_min[0][0], s_min[1][0], s_min[2][0]}, hi[3] = {s_max[0][0], s_max[1][0], s_max[2][0]};
-        for (int k = 0; k < 256; k++) {
-            all_ok &= s_ok[k];
-            for (int c = 0; c < 3; c++) {
-                if (s_min[c][k] < lo[c]) lo[c] = s_min[c][k];
-                if (s_max[c][k] > hi[c]) hi[c] = s_max[c][k];
-            }
-        }
         for (int c = 0; c < 3; c++) {
             hi[c] += shade_hi;   // taps in front of the back-most one carry colour + illumination
             // a filtered colour stays inside [lo, hi] up to one rounding; widen a little
