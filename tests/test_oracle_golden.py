@@ -45,6 +45,38 @@ def test_lut_quirks(oracle):
     assert np.isnan(lut[:, 0]).sum() == 1 and np.isnan(lut[255, 0])
 
 
+def test_lut_against_a_numpy_transliteration(oracle):
+    """updateTransferFunction (main.cpp:643-686) written out once more, statement by statement, in numpy float32
+    scalars (every operation rounded to float as the C++ expression rounds it: x / back.x, times 255.0f, the
+    float pixel count, k / (count - 1.0f), the float pixel index truncated for the subscript).  The checker's
+    table has to equal it bit for bit on every case, the ones that keep entries from earlier calls included."""
+    f = np.float32
+
+    def update(table, graphs):
+        for channel, graph in enumerate(graphs):
+            if not graph:
+                continue
+            back = f(graph[-1][0])
+            points = [(f(f(f(x) / back) * f(255.0)), f(v)) for x, v in graph]          # :649-658
+            for j in range(1, len(points)):                                               # :660-662
+                direction = f(points[j][1] - points[j - 1][1])                            # :663
+                total = f(f(points[j][0] - points[j - 1][0]) + f(1.0))                    # :664
+                for k in range(int(total) if total >= 1 else 0):                          # :665, exclusive
+                    value = f(points[j - 1][1] + f(direction * f(f(k) / f(total - f(1.0)))))   # :667
+                    pixel = f(points[j - 1][0] + f(k))                                    # :668
+                    table[int(pixel), channel] = value                                    # :669-680
+
+    with np.errstate(invalid="ignore", divide="ignore"):
+        for name, updates in cf.lut_cases().items():
+            mine = np.zeros((256, 4), np.float32)
+            theirs = np.zeros((256, 4), np.float32)
+            for graphs in updates:
+                update(mine, graphs)
+                assert oracle.lut_update(theirs, graphs) == 0
+            same = (mine.view(np.uint32) == theirs.view(np.uint32)) | (np.isnan(mine) & np.isnan(theirs))
+            assert same.all(), (name, np.argwhere(~same)[:4])
+
+
 def test_control_point_intensity(oracle):
     assert oracle.control_point_intensity(0.0, 300.0) == 1.0
     assert oracle.control_point_intensity(299.0, 300.0) == 0.0
