@@ -299,17 +299,26 @@ def test_normalize_matches_numpy(oracle):
 
 
 def test_histogram(oracle):
+    """prepareHistogramVolumeData (main.cpp:166-181) once more in numpy: sort, lower_bound of the float step * i,
+    upper_bound of the double step * (i + 0.9), the difference as a float, divided by the largest count.  All
+    100 bins bit for bit, on continuous values and on normalised integers (many ties, values on bin edges)."""
     rng = np.random.default_rng(2)
-    v = rng.random(5000).astype(np.float32)
-    h = oracle.histogram(v)
-    assert h.shape == (100,) and h.max() == 1.0 and h.min() > 0.0
-    s = np.sort(v)
-    step = np.float32(1.0) / np.float32(100)
-    for i in (0, 17, 99):
-        lo = np.searchsorted(s, np.float32(step * np.float32(i)), side="left")
-        hi = np.searchsorted(s.astype(np.float64), float(step) * (i + 0.9), side="right")
-        assert h[i] * max(1, round(float(h.max()))) >= 0
-        assert hi >= lo
+    u16 = (rng.random(20000) ** 2 * 4095).astype(np.uint16)
+    u8 = rng.integers(0, 256, 5000).astype(np.uint8)
+    cases = [rng.random(5000).astype(np.float32), oracle.normalize(u16.reshape(20, 25, 40))[0].ravel(),
+             oracle.normalize(u8.reshape(10, 20, 25))[0].ravel(), np.linspace(0, 1, 101, dtype=np.float32)]
+    step = np.float32(1.0) / np.float32(100)                                                  # :170
+    for v in cases:
+        got = oracle.histogram(v)
+        s = np.sort(v)                                                                        # :171
+        counts = np.zeros(100, np.float32)
+        for i in range(100):
+            lo = np.searchsorted(s, np.float32(step * np.float32(i)), side="left")            # :174
+            hi = np.searchsorted(s.astype(np.float64), float(step) * (i + 0.9), side="right")  # :175, double
+            counts[i] = np.float32(hi - lo)                                                   # :176
+        want = counts / np.float32(int(counts.max()))                                         # :178-180
+        assert got.shape == (100,) and cf.same_bits(got, want)
+        assert got.max() == 1.0
 
 
 def test_slice_loader_roundtrip(oracle, tmp_path):
